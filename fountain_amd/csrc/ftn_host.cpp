@@ -1,0 +1,668 @@
+/*
+ * ftn_host.cpp -- host side of libfountain_hip.so: the C ABI of include/fountain_hip.h.
+ *
+ *   - exact f32 restatements of the reference's host-only steps on the path: Transform algebra
+ *     (src/geometry/transform.rs), Sphere::new, PerspectiveCamera::new, Film::new / sample_bounds / tiles,
+ *     BVH::build (src/bvh.rs:27-158), Scene::new (src/scene/mod.rs:32-49), Distribution2D for env lights;
+ *   - scene flattening into the HBM layout of ftn_device.h;
+ *   - the render driver (SamplerIntegrator::render_parallel, src/integrator/mod.rs:218-227).
+ * There is no CPU fallback: every compute entry point needs a HIP device and fails with FTN_ERR_NO_DEVICE without one.
+ */
+#include "ftn_kernels.h"
+#include "ftn_wavefront.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ftn;
+
+static_assert(sizeof(ftn_transform) == 128 && sizeof(ftn_pixel) == 16 && sizeof(ftn_bvh_node) == 32 && sizeof(ftn_prim) == 16, "ABI");
+static_assert(sizeof(ftn_mesh) == 16 && sizeof(ftn_sphere) == 288 && sizeof(ftn_material) == 48 && sizeof(ftn_light) == 160, "ABI");
+static_assert(sizeof(ftn_envmap) == 16 && sizeof(ftn_camera_desc) == 296 && sizeof(ftn_film_desc) == 32 && sizeof(ftn_sampler_desc) == 24, "ABI");
+static_assert(sizeof(ftn_integrator_desc) == 16 && sizeof(ftn_tile_range) == 16 && sizeof(ftn_render_options) == 16 && sizeof(ftn_stats) == 96, "ABI");
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE, std::string(#expr ": ") + hipGetErrorString(e_)); } while (0)
+
+/* ================================================================== Transform algebra (cgmath 0.17 Matrix4 semantics) */
+static void m4_identity(float* m) { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+static void m4_mul(const float* l, const float* r, float* o) {   /* column j = l0*r[j][0] + l1*r[j][1] + l2*r[j][2] + l3*r[j][3] */
+    float t[16];
+    for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++)
+        t[j * 4 + i] = ((l[i] * r[j * 4] + l[4 + i] * r[j * 4 + 1]) + l[8 + i] * r[j * 4 + 2]) + l[12 + i] * r[j * 4 + 3];
+    memcpy(o, t, sizeof(t));
+}
+/* cgmath det_sub_proc_unsafe(m, x, y, z) */
+static void m4_det_sub(const float* s, int x, int y, int z, float out[4]) {
+    const float a[4] = {s[4 + x], s[12 + x], s[x], s[8 + x]}, b[4] = {s[8 + y], s[8 + y], s[4 + y], s[4 + y]}, c[4] = {s[12 + z], s[z], s[12 + z], s[z]};
+    const float d[4] = {s[8 + x], s[8 + x], s[4 + x], s[4 + x]}, e[4] = {s[12 + y], s[y], s[12 + y], s[y]}, f[4] = {s[4 + z], s[12 + z], s[z], s[8 + z]};
+    const float g[4] = {s[12 + x], s[x], s[12 + x], s[x]}, h[4] = {s[4 + y], s[12 + y], s[y], s[8 + y]}, i[4] = {s[8 + z], s[8 + z], s[4 + z], s[4 + z]};
+    for (int k = 0; k < 4; k++) {
+        float t = a[k] * (b[k] * c[k]);
+        t += d[k] * (e[k] * f[k]); t += g[k] * (h[k] * i[k]);
+        t -= a[k] * (e[k] * i[k]); t -= d[k] * (h[k] * c[k]); t -= g[k] * (b[k] * f[k]);
+        out[k] = t;
+    }
+}
+static float m4_det(const float* m) { float t[4]; m4_det_sub(m, 1, 2, 3, t); return ((t[0] * m[0] + t[1] * m[4]) + t[2] * m[8]) + t[3] * m[12]; }
+static bool m4_invert(const float* m, float* o) {
+    float t0[4], t1[4], t2[4], t3[4];
+    m4_det_sub(m, 1, 2, 3, t0);
+    float det = ((t0[0] * m[0] + t0[1] * m[4]) + t0[2] * m[8]) + t0[3] * m[12];
+    if (det == 0.0f) return false;
+    float inv_det = 1.0f / det;
+    m4_det_sub(m, 0, 3, 2, t1); m4_det_sub(m, 0, 1, 3, t2); m4_det_sub(m, 0, 2, 1, t3);
+    for (int k = 0; k < 4; k++) { o[k] = t0[k] * inv_det; o[4 + k] = t1[k] * inv_det; o[8 + k] = t2[k] * inv_det; o[12 + k] = t3[k] * inv_det; }
+    return true;
+}
+static void tf_mul(const ftn_transform* a, const ftn_transform* b, ftn_transform* o) {   /* transform.rs:143-149 */
+    ftn_transform r; m4_mul(a->m, b->m, r.m); m4_mul(b->inv, a->inv, r.inv); *o = r;
+}
+
+extern "C" {
+
+int ftn_transform_identity(ftn_transform* out) { m4_identity(out->m); m4_identity(out->inv); return FTN_OK; }
+int ftn_transform_translate(const float d[3], ftn_transform* out) {              /* :62-66 */
+    m4_identity(out->m); m4_identity(out->inv);
+    for (int i = 0; i < 3; i++) { out->m[12 + i] = d[i]; out->inv[12 + i] = -d[i]; }
+    return FTN_OK;
+}
+int ftn_transform_scale(float sx, float sy, float sz, ftn_transform* out) {      /* :68-72 */
+    m4_identity(out->m); m4_identity(out->inv);
+    out->m[0] = sx; out->m[5] = sy; out->m[10] = sz;
+    out->inv[0] = 1.0f / sx; out->inv[5] = 1.0f / sy; out->inv[10] = 1.0f / sz;
+    return FTN_OK;
+}
+int ftn_transform_from_flat(const float m[16], ftn_transform* out) {             /* :23-39 */
+    ftn_transform r; memcpy(r.m, m, 64);
+    if (!m4_invert(r.m, r.inv)) return fail(FTN_ERR_INVALID_ARGUMENT, "Could not invert matrix");
+    *out = r; return FTN_OK;
+}
+int ftn_transform_rotate(float angle_deg, const float axis[3], ftn_transform* out) {   /* :74-78; Matrix4::from_axis_angle */
+    V3 a = normalize(V3(axis[0], axis[1], axis[2]));
+    float ang = angle_deg * (float)(3.14159265358979323846 / 180.0);             /* Rad::from(Deg) */
+    float s = ftn_det::sinf_det(ang), c = ftn_det::cosf_det(ang), omc = 1.0f - c;
+    float f[16] = {omc * a.x * a.x + c,       omc * a.x * a.y + s * a.z, omc * a.x * a.z - s * a.y, 0.0f,
+                   omc * a.x * a.y - s * a.z, omc * a.y * a.y + c,       omc * a.y * a.z + s * a.x, 0.0f,
+                   omc * a.x * a.z + s * a.y, omc * a.y * a.z - s * a.x, omc * a.z * a.z + c,       0.0f,
+                   0.0f, 0.0f, 0.0f, 1.0f};
+    return ftn_transform_from_flat(f, out);
+}
+int ftn_transform_look_at(const float p[3], const float l[3], const float u[3], ftn_transform* out) {   /* :41-56 */
+    V3 pos(p[0], p[1], p[2]);
+    V3 dir = normalize(V3(l[0], l[1], l[2]) - pos);
+    V3 right = normalize(cross(normalize(V3(u[0], u[1], u[2])), dir));
+    V3 new_up = cross(dir, right);
+    float mat[16] = {right.x, right.y, right.z, 0.0f, new_up.x, new_up.y, new_up.z, 0.0f, dir.x, dir.y, dir.z, 0.0f, pos.x, pos.y, pos.z, 1.0f};
+    ftn_transform r; memcpy(r.inv, mat, 64);
+    if (!m4_invert(mat, r.m)) return fail(FTN_ERR_INVALID_ARGUMENT, "Could not invert matrix");
+    *out = r; return FTN_OK;
+}
+int ftn_transform_mul(const ftn_transform* a, const ftn_transform* b, ftn_transform* out) { tf_mul(a, b, out); return FTN_OK; }
+int ftn_transform_inverse(const ftn_transform* a, ftn_transform* out) { ftn_transform r; memcpy(r.m, a->inv, 64); memcpy(r.inv, a->m, 64); *out = r; return FTN_OK; }
+int ftn_transform_perspective(float fov, float n, float f, ftn_transform* out) {   /* :105-115 */
+    float m[16] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, f / (f - n), 1.0f, 0.0f, 0.0f, -f * n / (f - n), 0.0f};
+    float inv_tan_ang = 1.0f / ftn_det::tanf_det((fov * (FTN_PI / 180.0f)) / 2.0f);   /* f32::to_radians */
+    ftn_transform p, s;
+    int rc = ftn_transform_from_flat(m, &p); if (rc) return rc;
+    ftn_transform_scale(inv_tan_ang, inv_tan_ang, 1.0f, &s);
+    tf_mul(&s, &p, out);
+    return FTN_OK;
+}
+int ftn_transform_point(const ftn_transform* t, const float p[3], float o[3]) { V3 r = m4_point(t->m, V3(p[0], p[1], p[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return FTN_OK; }
+int ftn_transform_vector(const ftn_transform* t, const float p[3], float o[3]) { V3 r = m4_vector(t->m, V3(p[0], p[1], p[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return FTN_OK; }
+int ftn_transform_normal(const ftn_transform* t, const float p[3], float o[3]) { V3 r = m4_normal(t->inv, V3(p[0], p[1], p[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return FTN_OK; }
+int ftn_transform_swaps_handedness(const ftn_transform* t) { return m4_det(t->m) < 0.0f ? 1 : 0; }
+int ftn_transform_points(const ftn_transform* t, size_t n, const float* in, float* out) {
+    for (size_t i = 0; i < n; i++) { V3 r = m4_point(t->m, V3(in[3 * i], in[3 * i + 1], in[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+    return FTN_OK;
+}
+int ftn_transform_normals(const ftn_transform* t, size_t n, const float* in, float* out) {
+    for (size_t i = 0; i < n; i++) { V3 r = m4_normal(t->inv, V3(in[3 * i], in[3 * i + 1], in[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+    return FTN_OK;
+}
+
+/* ================================================================== Sphere::new / PerspectiveCamera::new / Film */
+int ftn_sphere_init(const ftn_transform* o2w, const ftn_transform* w2o, int rev, float radius, float z_min, float z_max, float phi_max_deg, ftn_sphere* out) {
+    memset(out, 0, sizeof(*out));                                                 /* sphere.rs:30-50 */
+    out->object_to_world = *o2w; out->world_to_object = *w2o; out->reverse_orientation = rev ? 1u : 0u;
+    out->radius = radius;
+    out->z_min = clampf(fmin_(z_min, z_max), -radius, radius);
+    out->z_max = clampf(fmax_(z_min, z_max), -radius, radius);
+    out->theta_min = ftn_det::acosf_det(clampf(z_min / radius, -1.0f, 1.0f));
+    out->theta_max = ftn_det::acosf_det(clampf(z_max / radius, -1.0f, 1.0f));
+    out->phi_max = clampf(phi_max_deg, 0.0f, 360.0f) * (FTN_PI / 180.0f);
+    return FTN_OK;
+}
+int ftn_camera_perspective(const ftn_transform* c2w, const int32_t res[2], const float sw[4], const float sh[2], float lens_radius, float focal_dist,
+                           float fov, ftn_camera_desc* out) {                   /* camera/mod.rs:51-69, 85-114 */
+    memset(out, 0, sizeof(*out));
+    ftn_transform persp, s1, s2, tr, s2r, s2r_inv, pinv, r2c;
+    int rc = ftn_transform_perspective(fov, 1.0e-2f, 1000.0f, &persp); if (rc) return rc;
+    ftn_transform_scale((float)res[0], (float)res[1], 1.0f, &s1);
+    ftn_transform_scale(1.0f / (sw[2] - sw[0]), 1.0f / (sw[1] - sw[3]), 1.0f, &s2);
+    const float d[3] = {-sw[0], -sw[3], 0.0f};
+    ftn_transform_translate(d, &tr);
+    ftn_transform t12; tf_mul(&s1, &s2, &t12); tf_mul(&t12, &tr, &s2r);           /* screen_to_raster */
+    ftn_transform_inverse(&s2r, &s2r_inv);                                       /* raster_to_screen */
+    ftn_transform_inverse(&persp, &pinv);
+    tf_mul(&pinv, &s2r_inv, &r2c);                                               /* raster_to_camera */
+    out->camera_to_world = *c2w; out->raster_to_camera = r2c;
+    out->shutter_open = sh[0]; out->shutter_close = sh[1]; out->lens_radius = lens_radius; out->focal_dist = focal_dist;
+    V3 o = m4_point(r2c.m, V3(0.0f, 0.0f, 0.0f));
+    V3 dx = m4_point(r2c.m, V3(1.0f, 0.0f, 0.0f)) - o, dy = m4_point(r2c.m, V3(0.0f, 1.0f, 0.0f)) - o;
+    out->dx_camera[0] = dx.x; out->dx_camera[1] = dx.y; out->dx_camera[2] = dx.z;
+    out->dy_camera[0] = dy.x; out->dy_camera[1] = dy.y; out->dy_camera[2] = dy.z;
+    return FTN_OK;
+}
+int ftn_film_init(const int32_t res[2], const float cw[4], ftn_film_desc* out) {   /* film.rs:43-58 */
+    out->full_resolution[0] = res[0]; out->full_resolution[1] = res[1];
+    out->crop[0] = f2i_sat(ceilf((float)res[0] * cw[0])); out->crop[1] = f2i_sat(ceilf((float)res[1] * cw[1]));
+    out->crop[2] = f2i_sat(ceilf((float)res[0] * cw[2])); out->crop[3] = f2i_sat(ceilf((float)res[1] * cw[3]));
+    out->filter_radius[0] = 0.5f; out->filter_radius[1] = 0.5f;
+    return FTN_OK;
+}
+int ftn_film_sample_bounds(const ftn_film_desc* f, int32_t o[4]) {                 /* film.rs:86-93 */
+    o[0] = f2i_sat(floorf((float)f->crop[0] + 0.5f - f->filter_radius[0])); o[1] = f2i_sat(floorf((float)f->crop[1] + 0.5f - f->filter_radius[1]));
+    o[2] = f2i_sat(ceilf((float)f->crop[2] - 0.5f + f->filter_radius[0])); o[3] = f2i_sat(ceilf((float)f->crop[3] - 0.5f + f->filter_radius[1]));
+    return FTN_OK;
+}
+static void list_tiles(const ftn_film_desc* f, std::vector<DTile>* tiles) {        /* bounds.rs:85-97, integrator/mod.rs:182-185 */
+    int32_t sb[4]; ftn_film_sample_bounds(f, sb);
+    for (int y = sb[1]; y < sb[3]; y += 16) for (int x = sb[0]; x < sb[2]; x += 16) {
+        DTile t; t.x0 = x; t.y0 = y; t.x1 = std::min(x + 16, sb[2]); t.y1 = std::min(y + 16, sb[3]);
+        t.tile_id = (unsigned long long)(long long)(t.y0 * sb[2] + t.x0);
+        tiles->push_back(t);
+    }
+}
+int ftn_film_tile_count(const ftn_film_desc* f, uint32_t* out) { std::vector<DTile> t; list_tiles(f, &t); *out = (uint32_t)t.size(); return FTN_OK; }
+int ftn_film_resolve(const ftn_pixel* p, size_t n, float* rgb_out) {               /* film.rs:195-210 (host buffers; output stage) */
+    for (size_t i = 0; i < n; i++) {
+        float rgb[3]; xyz_to_rgb(p[i].xyz, rgb);
+        if (p[i].filter_weight_sum != 0.0f) { float inv = 1.0f / p[i].filter_weight_sum; for (int c = 0; c < 3; c++) rgb[c] = fmax_(0.0f, rgb[c] * inv); }
+        rgb_out[3 * i] = rgb[0]; rgb_out[3 * i + 1] = rgb[1]; rgb_out[3 * i + 2] = rgb[2];
+    }
+    return FTN_OK;
+}
+
+}  /* extern "C" */
+
+/* ================================================================== BVH::build (bvh.rs:27-158), written directly in flattened DFS order */
+namespace {
+
+struct Aabb { float lo[3], hi[3]; };
+static const float kFmax = 3.402823466e+38f;
+static Aabb aabb_empty() { Aabb b; for (int i = 0; i < 3; i++) { b.lo[i] = kFmax; b.hi[i] = -kFmax; } return b; }
+static void aabb_join_point(Aabb& b, V3 p) { b.lo[0] = fmin_(b.lo[0], p.x); b.lo[1] = fmin_(b.lo[1], p.y); b.lo[2] = fmin_(b.lo[2], p.z); b.hi[0] = fmax_(b.hi[0], p.x); b.hi[1] = fmax_(b.hi[1], p.y); b.hi[2] = fmax_(b.hi[2], p.z); }
+
+struct BvhBuilder {
+    const std::vector<Aabb>& bounds; std::vector<float> centroid;   /* 3 per prim */
+    std::vector<uint32_t> order;                                     /* permutation being partitioned */
+    std::vector<ftn_bvh_node> nodes; std::vector<uint32_t> leaf_order; uint32_t max_depth = 0;
+    explicit BvhBuilder(const std::vector<Aabb>& b) : bounds(b) {
+        size_t n = b.size(); centroid.resize(3 * n); order.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            order[i] = (uint32_t)i;
+            for (int k = 0; k < 3; k++) centroid[3 * i + k] = b[i].lo[k] + ((b[i].hi[k] - b[i].lo[k]) / 2.0f);   /* Bounds3::centroid bounds.rs:160-162 */
+        }
+        nodes.reserve(2 * n); leaf_order.reserve(n);
+    }
+    void build(size_t lo, size_t hi, uint32_t depth) {               /* recursive_build :66-120 + flatten_tree :133-158 */
+        if (depth > max_depth) max_depth = depth;
+        Aabb nb = aabb_empty(), cb = aabb_empty();
+        for (size_t i = lo; i < hi; i++) {
+            const uint32_t p = order[i]; const Aabb& b = bounds[p];
+            for (int k = 0; k < 3; k++) { nb.lo[k] = fmin_(nb.lo[k], b.lo[k]); nb.hi[k] = fmax_(nb.hi[k], b.hi[k]); cb.lo[k] = fmin_(cb.lo[k], centroid[3 * p + k]); cb.hi[k] = fmax_(cb.hi[k], centroid[3 * p + k]); }
+        }
+        ftn_bvh_node node; memset(&node, 0, sizeof(node));
+        for (int k = 0; k < 3; k++) { node.bmin[k] = nb.lo[k]; node.bmax[k] = nb.hi[k]; }
+        const size_t n = hi - lo;
+        const bool is_point = cb.lo[0] == cb.hi[0] && cb.lo[1] == cb.hi[1] && cb.lo[2] == cb.hi[2];
+        if (n == 1 || is_point) {
+            node.is_leaf = 1; node.idx = (uint32_t)leaf_order.size(); node.n_prims = (uint16_t)n;
+            for (size_t i = lo; i < hi; i++) leaf_order.push_back(order[i]);
+            nodes.push_back(node);
+            return;
+        }
+        const float dx = cb.hi[0] - cb.lo[0], dy = cb.hi[1] - cb.lo[1], dz = cb.hi[2] - cb.lo[2];
+        const int ax = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);                 /* maximum_extent bounds.rs:168-177 */
+        const float mid = (cb.lo[ax] + cb.hi[ax]) / 2.0f;
+        uint32_t* first = order.data() + lo; uint32_t* last = order.data() + hi;
+        uint32_t* split = std::partition(first, last, [&](uint32_t p) { return centroid[3 * p + ax] < mid; });
+        size_t m = (size_t)(split - first);
+        if (m == 0 || m == n) {                                                    /* partition_equal_counts :122-131 */
+            m = n / 2;
+            std::nth_element(first, first + m, last, [&](uint32_t a, uint32_t b) { return centroid[3 * a + ax] < centroid[3 * b + ax]; });
+        }
+        node.is_leaf = 0; node.axis = (uint8_t)ax; node.idx = 0;
+        const size_t my = nodes.size();
+        nodes.push_back(node);
+        build(lo, lo + m, depth + 1);
+        nodes[my].idx = (uint32_t)nodes.size();                                    /* second_child_idx = my + first_subtree_len + 1 */
+        build(lo + m, hi, depth + 1);
+    }
+};
+
+struct HostScene {
+    std::vector<ftn_bvh_node> nodes; std::vector<uint32_t> order; uint32_t max_depth = 0; Aabb world;
+    std::vector<int32_t> light_kind, light_prim;
+};
+
+static Aabb prim_bounds(const ftn_scene_desc* d, const ftn_prim& p) {
+    Aabb b = aabb_empty();
+    if (p.shape_kind == FTN_SHAPE_TRIANGLE) {                                      /* Triangle::world_bound triangle.rs:152-158 */
+        for (int k = 0; k < 3; k++) { uint32_t v = d->tri_indices[3 * (size_t)p.shape_index + k]; aabb_join_point(b, V3(d->P[3 * v], d->P[3 * v + 1], d->P[3 * v + 2])); }
+    } else {                                                                       /* Shape::world_bound default + Bounds3f::transform, shapes/mod.rs:13-15 */
+        const ftn_sphere& s = d->spheres[p.shape_index];
+        const float lo[3] = {-s.radius, -s.radius, s.z_min}, hi[3] = {s.radius, s.radius, s.z_max};
+        for (int c = 0; c < 8; c++) {                                              /* iter_corners order bounds.rs:183-194 */
+            V3 q((c & 4) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 1) ? hi[2] : lo[2]);
+            aabb_join_point(b, m4_point(s.object_to_world.m, q));
+        }
+    }
+    return b;
+}
+static int validate_desc(const ftn_scene_desc* d) {
+    if (!d) return fail(FTN_ERR_INVALID_ARGUMENT, "null scene description");
+    for (uint32_t i = 0; i < d->n_triangles; i++) {
+        if (d->tri_mesh[i] >= d->n_meshes) return fail(FTN_ERR_INVALID_ARGUMENT, "triangle mesh id out of range");
+        for (int k = 0; k < 3; k++) if (d->tri_indices[3 * (size_t)i + k] >= d->n_vertices) return fail(FTN_ERR_INVALID_ARGUMENT, "vertex index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+        const ftn_prim& p = d->prims[i];
+        if (p.shape_kind == FTN_SHAPE_TRIANGLE) { if (p.shape_index >= d->n_triangles) return fail(FTN_ERR_INVALID_ARGUMENT, "triangle index out of range"); }
+        else if (p.shape_kind == FTN_SHAPE_SPHERE) { if (p.shape_index >= d->n_spheres) return fail(FTN_ERR_INVALID_ARGUMENT, "sphere index out of range"); }
+        else return fail(FTN_ERR_INVALID_ARGUMENT, "unknown shape kind");
+        if (p.material >= (int)d->n_materials || p.area_emit >= (int)d->n_area_emit) return fail(FTN_ERR_INVALID_ARGUMENT, "material / area light index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_envmaps; i++) {
+        uint32_t w = d->envmaps[i].width, h = d->envmaps[i].height;
+        if (w != h || w == 0 || (w & (w - 1))) return fail(FTN_ERR_UNSUPPORTED, "environment maps must be square with a power-of-two side");
+    }
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        if (d->lights[i].type > FTN_LIGHT_INFINITE) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown light type");
+        if (d->lights[i].type == FTN_LIGHT_INFINITE && (d->lights[i].envmap < 0 || d->lights[i].envmap >= (int)d->n_envmaps)) return fail(FTN_ERR_INVALID_ARGUMENT, "envmap index out of range");
+    }
+    return FTN_OK;
+}
+static int build_host_scene(const ftn_scene_desc* d, HostScene* hs) {
+    int rc = validate_desc(d); if (rc) return rc;
+    std::vector<Aabb> pb(d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; i++) pb[i] = prim_bounds(d, d->prims[i]);
+    hs->world = aabb_empty();
+    if (d->n_prims) {
+        BvhBuilder b(pb);
+        b.build(0, d->n_prims, 0);
+        hs->nodes.swap(b.nodes); hs->order.swap(b.leaf_order); hs->max_depth = b.max_depth;
+        for (int k = 0; k < 3; k++) { hs->world.lo[k] = hs->nodes[0].bmin[k]; hs->world.hi[k] = hs->nodes[0].bmax[k]; }
+    }
+    /* Scene::new (scene/mod.rs:32-49): explicit lights first, then one area light per emissive primitive in BVH order */
+    for (uint32_t i = 0; i < d->n_lights; i++) { hs->light_kind.push_back((int)d->lights[i].type); hs->light_prim.push_back(-1); }
+    for (size_t i = 0; i < hs->order.size(); i++) if (d->prims[hs->order[i]].area_emit >= 0) { hs->light_kind.push_back((int)LK_AREA); hs->light_prim.push_back((int)i); }
+    return FTN_OK;
+}
+
+/* Distribution1D::new (sampling.rs:84-107) into flat arrays */
+static float dist1d_build(const float* f, size_t n, float* cdf) {
+    cdf[0] = 0.0f;
+    for (size_t i = 1; i < n + 1; i++) cdf[i] = cdf[i - 1] + (f[i - 1] / (float)n);
+    float integral = cdf[n];
+    if (integral == 0.0f) { for (size_t i = 1; i < n + 1; i++) cdf[i] = (float)i / (float)n; }
+    else { for (size_t i = 1; i < n + 1; i++) cdf[i] /= integral; }
+    return integral;
+}
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int upload(const T* src, size_t count) {
+        n = count; if (!count) return FTN_OK;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        return FTN_OK;
+    }
+    int alloc_zero(size_t count) {
+        n = count; if (!count) return FTN_OK;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        HIP_TRY(hipMemset(p, 0, count * sizeof(T)));
+        return FTN_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct ftn_scene {
+    int device = 0;
+    HostScene host;
+    DScene d; uint32_t stack_entries = 1;
+    DevBuf<float4> nodes, geom; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
+    DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc;
+    /* render work buffers (grow-only, reused across calls) */
+    DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
+    WavefrontState* wf = nullptr;
+    ~ftn_scene() {
+        nodes.release(); geom.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
+        for (auto& b : misc) b.release();
+        accA.release(); accB.release(); accC.release(); tiles.release(); stats.release();
+        wavefront_destroy(wf);
+    }
+};
+
+static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
+    const HostScene& hs = sc->host;
+    const size_t np = hs.order.size();
+    std::vector<float4> nodes(2 * hs.nodes.size());
+    for (size_t i = 0; i < hs.nodes.size(); i++) {
+        const ftn_bvh_node& n = hs.nodes[i];
+        nodes[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], ftn_det::u2f(n.idx));
+        nodes[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], ftn_det::u2f((uint32_t)n.n_prims | ((uint32_t)n.axis << 16) | ((uint32_t)n.is_leaf << 24)));
+    }
+    std::vector<int> prim_light(np, -1);
+    for (size_t l = 0; l < hs.light_prim.size(); l++) if (hs.light_prim[l] >= 0) prim_light[hs.light_prim[l]] = (int)l;
+    std::vector<float4> geom(3 * np); std::vector<uint4> info(2 * np);
+    for (size_t i = 0; i < np; i++) {
+        const ftn_prim& p = d->prims[hs.order[i]];
+        uint32_t fl = 0;
+        if (p.shape_kind == FTN_SHAPE_SPHERE) {
+            fl = GF_KIND_SPHERE;
+            geom[3 * i] = make_float4(0, 0, 0, ftn_det::u2f(fl)); geom[3 * i + 1] = make_float4(0, 0, 0, ftn_det::u2f(p.shape_index)); geom[3 * i + 2] = make_float4(0, 0, 0, 0);
+            info[2 * i + 1] = make_uint4(0, 0, 0, p.shape_index);
+        } else {
+            const ftn_mesh& m = d->meshes[d->tri_mesh[p.shape_index]];
+            if (m.has_normals && d->N) fl |= GF_HAS_NORMALS;
+            if (m.has_uvs && d->UV) fl |= GF_HAS_UVS;
+            if (m.flip_normals) fl |= GF_FLIP;
+            const uint32_t* vi = d->tri_indices + 3 * (size_t)p.shape_index;
+            const float* P = d->P;
+            geom[3 * i] = make_float4(P[3 * vi[0]], P[3 * vi[0] + 1], P[3 * vi[0] + 2], ftn_det::u2f(fl));
+            geom[3 * i + 1] = make_float4(P[3 * vi[1]], P[3 * vi[1] + 1], P[3 * vi[1] + 2], ftn_det::u2f(p.shape_index));
+            geom[3 * i + 2] = make_float4(P[3 * vi[2]], P[3 * vi[2] + 1], P[3 * vi[2] + 2], 0.0f);
+            info[2 * i + 1] = make_uint4(vi[0], vi[1], vi[2], p.shape_index);
+        }
+        info[2 * i] = make_uint4((uint32_t)p.material, (uint32_t)prim_light[i], fl, 0);
+    }
+    int rc;
+    if ((rc = sc->nodes.upload(nodes.data(), nodes.size()))) return rc;
+    if ((rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
+    if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
+    if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
+    if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
+    std::vector<DSphere> sph(d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        const ftn_sphere& s = d->spheres[i]; DSphere& o = sph[i];
+        memcpy(o.o2w, s.object_to_world.m, 64); memcpy(o.o2w_inv, s.object_to_world.inv, 64); memcpy(o.w2o, s.world_to_object.m, 64);
+        o.radius = s.radius; o.z_min = s.z_min; o.z_max = s.z_max; o.theta_min = s.theta_min; o.theta_max = s.theta_max; o.phi_max = s.phi_max;
+        o.reverse_orientation = s.reverse_orientation; o._pad = 0;
+    }
+    if ((rc = sc->spheres.upload(sph.data(), sph.size()))) return rc;
+    /* materials: evaluate the constant-per-material parts of compute_scattering_functions once */
+    std::vector<ftn_material> mats(d->materials, d->materials + d->n_materials);
+    for (auto& m : mats) {
+        auto r2a = [](float roughness) {                                          /* roughness_to_alpha microfacet.rs:40-45 */
+            float x = ftn_det::logf_det(fmax_(roughness, 1.0e-3f));
+            return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+        };
+        if (m.type == FTN_MAT_MATTE) {                                            /* matte.rs:39-50, OrenNayar::new reflection/mod.rs:260-267 */
+            m.s0 = clampf(m.s0, 0.0f, 90.0f);
+            if (m.s0 != 0.0f) { float sg = m.s0 * (float)(3.14159265358979323846 / 180.0); float s2 = sg * sg; m.s1 = 1.0f - (s2 / (2.0f * (s2 + 0.33f))); m.s2 = 0.45f * s2 / (s2 + 0.09f); }
+        } else if (m.type == FTN_MAT_METAL || m.type == FTN_MAT_GLASS) { if (m.remap_roughness) { m.s1 = r2a(m.s1); m.s2 = r2a(m.s2); m.remap_roughness = 0; } }
+        else if (m.type == FTN_MAT_PLASTIC) { if (m.remap_roughness) { m.s1 = r2a(m.s1); m.remap_roughness = 0; } }
+    }
+    if ((rc = sc->materials.upload(mats.data(), mats.size()))) return rc;
+    /* lights */
+    std::vector<DLight> lights(hs.light_kind.size());
+    std::vector<uint32_t> inf;
+    V3 wc((hs.world.lo[0] + hs.world.hi[0]) / 2.0f, (hs.world.lo[1] + hs.world.hi[1]) / 2.0f, (hs.world.lo[2] + hs.world.hi[2]) / 2.0f);   /* bounding_sphere bounds.rs:208-212 */
+    wc = V3(0.0f, 0.0f, 0.0f) + wc;
+    float wr = len(wc - V3(hs.world.hi[0], hs.world.hi[1], hs.world.hi[2]));
+    for (size_t l = 0; l < lights.size(); l++) {
+        DLight& L = lights[l]; memset(&L, 0, sizeof(L));
+        L.kind = (uint32_t)hs.light_kind[l]; L.prim = hs.light_prim[l];
+        if (L.kind == LK_AREA) {
+            const ftn_prim& p = d->prims[hs.order[L.prim]];
+            for (int k = 0; k < 3; k++) L.rgb[k] = d->area_emit[3 * p.area_emit + k];
+            if (p.shape_kind == FTN_SHAPE_SPHERE) { const ftn_sphere& s = d->spheres[p.shape_index]; L.area = s.phi_max * s.radius * (s.z_max - s.z_min); }   /* sphere.rs:77-79 */
+            else {                                                                /* triangle.rs:171-174 */
+                const uint32_t* vi = d->tri_indices + 3 * (size_t)p.shape_index; const float* P = d->P;
+                V3 p0(P[3 * vi[0]], P[3 * vi[0] + 1], P[3 * vi[0] + 2]), p1(P[3 * vi[1]], P[3 * vi[1] + 1], P[3 * vi[1] + 2]), p2(P[3 * vi[2]], P[3 * vi[2] + 1], P[3 * vi[2] + 2]);
+                L.area = 0.5f * len(cross(p1 - p0, p2 - p0));
+            }
+            continue;
+        }
+        const ftn_light& src = d->lights[l];
+        for (int k = 0; k < 3; k++) { L.rgb[k] = src.rgb[k]; L.v[k] = src.v[k]; }
+        if (L.kind == LK_DISTANT || L.kind == LK_INFINITE) { L.world_center[0] = wc.x; L.world_center[1] = wc.y; L.world_center[2] = wc.z; L.world_radius = wr; }   /* preprocess */
+        if (L.kind == LK_INFINITE) {
+            inf.push_back((uint32_t)l);
+            const ftn_envmap& e = d->envmaps[src.envmap];
+            memcpy(L.l2w, src.light_to_world.m, 64); memcpy(L.w2l, src.light_to_world.inv, 64);
+            L.env_w = e.width; L.env_h = e.height;
+            /* compute_distribution infinite.rs:63-78: (height, width) = resolution() name swap, square maps only; level = 0 exactly */
+            const uint32_t height = e.width, width = e.height;
+            DLight hostL = L; hostL.texels = e.texels;
+            std::vector<float> img((size_t)width * height);
+            for (uint32_t j = 0; j < height; j++) {
+                float v = (float)j / (float)height;
+                float sin_theta = ftn_det::sinf_det(FTN_PI * ((float)j + 0.5f) / (float)height);
+                for (uint32_t i = 0; i < width; i++) {
+                    float u = (float)i / (float)width;
+                    Rgb tex = (e.width == 1 && e.height == 1) ? env_texel(hostL, 0, 0) : env_lookup(hostL, V2(u, v));
+                    img[i + (size_t)j * width] = tex.luminance() * sin_theta;
+                }
+            }
+            const uint32_t nu = width, nv = height;
+            std::vector<float> ccdf((size_t)nv * (nu + 1)), cint(nv), mcdf(nv + 1);
+            for (uint32_t v2 = 0; v2 < nv; v2++) cint[v2] = dist1d_build(&img[(size_t)v2 * nu], nu, &ccdf[(size_t)v2 * (nu + 1)]);
+            float mint = dist1d_build(cint.data(), nv, mcdf.data());
+            L.nu = nu; L.nv = nv; L.marg_integral = mint;
+            DevBuf<float> b0, b1, b2, b3, b4, b5;
+            if ((rc = b0.upload(e.texels, (size_t)e.width * e.height * 3))) return rc;
+            if ((rc = b1.upload(img.data(), img.size()))) return rc;
+            if ((rc = b2.upload(ccdf.data(), ccdf.size()))) return rc;
+            if ((rc = b3.upload(cint.data(), cint.size()))) return rc;
+            if ((rc = b4.upload(cint.data(), cint.size()))) return rc;             /* marginal func == conditional integrals */
+            if ((rc = b5.upload(mcdf.data(), mcdf.size()))) return rc;
+            L.texels = b0.p; L.cond_func = b1.p; L.cond_cdf = b2.p; L.cond_integral = b3.p; L.marg_func = b4.p; L.marg_cdf = b5.p;
+            sc->misc.push_back(b0); sc->misc.push_back(b1); sc->misc.push_back(b2); sc->misc.push_back(b3); sc->misc.push_back(b4); sc->misc.push_back(b5);
+        }
+    }
+    if ((rc = sc->lights.upload(lights.data(), lights.size()))) return rc;
+    if ((rc = sc->inf_lights.upload(inf.data(), inf.size()))) return rc;
+    DScene& D = sc->d; memset(&D, 0, sizeof(D));
+    D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.spheres = sc->spheres.p;
+    D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
+    D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size();
+    sc->stack_entries = std::max<uint32_t>(hs.max_depth, 1u);
+    if ((rc = sc->stats.alloc_zero(1))) return rc;
+    return FTN_OK;
+}
+
+static int set_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(FTN_ERR_NO_DEVICE, "no HIP device available: the fountain HIP path needs an AMD GPU (there is no CPU fallback)");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    return FTN_OK;
+}
+
+extern "C" {
+
+const char* ftn_last_error(void) { return g_err.c_str(); }
+const char* ftn_version(void) { return "fountain_hip 0.1 (gfx950)"; }
+int ftn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int ftn_bvh_build(const ftn_scene_desc* d, ftn_bvh_node* nodes_out, uint32_t* order_out, uint32_t* n_nodes_out, uint32_t* max_depth_out) {
+    HostScene hs; int rc = build_host_scene(d, &hs); if (rc) return rc;
+    if (nodes_out) memcpy(nodes_out, hs.nodes.data(), hs.nodes.size() * sizeof(ftn_bvh_node));
+    if (order_out) memcpy(order_out, hs.order.data(), hs.order.size() * sizeof(uint32_t));
+    if (n_nodes_out) *n_nodes_out = (uint32_t)hs.nodes.size();
+    if (max_depth_out) *max_depth_out = hs.max_depth;
+    return FTN_OK;
+}
+
+int ftn_scene_create(const ftn_scene_desc* d, int device, ftn_scene** out) {
+    if (!out) return fail(FTN_ERR_INVALID_ARGUMENT, "null output");
+    int rc = set_device(device); if (rc) return rc;
+    ftn_scene* sc = new ftn_scene();
+    sc->device = device;
+    rc = build_host_scene(d, &sc->host);
+    if (!rc && sc->host.max_depth > 64) rc = fail(FTN_ERR_BVH_TOO_DEEP, "BVH deeper than the reference's 64-entry traversal stack (bvh.rs:168)");
+    if (!rc) rc = upload_scene(d, sc);
+    if (rc) { delete sc; return rc; }
+    *out = sc; return FTN_OK;
+}
+void ftn_scene_destroy(ftn_scene* s) { delete s; }
+int ftn_scene_info(const ftn_scene* s, uint32_t* n_nodes, uint32_t* n_prims, uint32_t* n_lights, uint32_t* max_depth, float wb[6]) {
+    if (n_nodes) *n_nodes = (uint32_t)s->host.nodes.size();
+    if (n_prims) *n_prims = (uint32_t)s->host.order.size();
+    if (n_lights) *n_lights = (uint32_t)s->host.light_kind.size();
+    if (max_depth) *max_depth = s->host.max_depth;
+    if (wb) for (int i = 0; i < 3; i++) { wb[i] = s->host.world.lo[i]; wb[3 + i] = s->host.world.hi[i]; }
+    return FTN_OK;
+}
+int ftn_scene_get_nodes(const ftn_scene* s, ftn_bvh_node* nodes, uint32_t* order) {
+    if (nodes) memcpy(nodes, s->host.nodes.data(), s->host.nodes.size() * sizeof(ftn_bvh_node));
+    if (order) memcpy(order, s->host.order.data(), s->host.order.size() * sizeof(uint32_t));
+    return FTN_OK;
+}
+int ftn_scene_get_lights(const ftn_scene* s, int32_t* kind, int32_t* prim) {
+    for (size_t i = 0; i < s->host.light_kind.size(); i++) { kind[i] = s->host.light_kind[i]; prim[i] = s->host.light_prim[i]; }
+    return FTN_OK;
+}
+
+/* ------------------------------------------------------------------ batch intersection */
+static void stats_out(const DevStats& ds, ftn_stats* st, double ms) {
+    if (!st) return;
+    memset(st, 0, sizeof(*st));
+    st->rays_closest = ds.rays_closest; st->rays_any = ds.rays_any; st->nodes_visited = ds.nodes_visited; st->prims_tested = ds.prims_tested;
+    st->camera_samples = ds.camera_samples; st->spill_samples = ds.spill_samples; st->kernel_ms = ms;
+}
+static int trace_batch(const ftn_scene* cs, const float* rays, size_t n, int mode, float* t_hit, int32_t* prim, float* bary, uint8_t* occ, float* out24, ftn_stats* st) {
+    ftn_scene* s = const_cast<ftn_scene*>(cs);
+    int rc = set_device(s->device); if (rc) return rc;
+    DevBuf<float> d_rays, d_t, d_b, d_o; DevBuf<int> d_p; DevBuf<unsigned char> d_occ;
+    auto cleanup = [&]() { d_rays.release(); d_t.release(); d_b.release(); d_o.release(); d_p.release(); d_occ.release(); };
+    if ((rc = d_rays.upload(rays, 8 * n))) { cleanup(); return rc; }
+    if (mode == 0) { if ((rc = d_t.alloc_zero(n)) || (rc = d_p.alloc_zero(n)) || (rc = d_b.alloc_zero(3 * n))) { cleanup(); return rc; } }
+    else if (mode == 1) { if ((rc = d_occ.alloc_zero(n))) { cleanup(); return rc; } }
+    else { if ((rc = d_o.alloc_zero(24 * n))) { cleanup(); return rc; } }
+    HIP_TRY(hipMemset(s->stats.p, 0, sizeof(DevStats)));
+    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    launch_trace_batch(s->d, d_rays.p, n, mode, d_t.p, d_p.p, d_b.p, d_occ.p, d_o.p, s->stats.p, s->stack_entries, st != nullptr, 0);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (t_hit) HIP_TRY(hipMemcpy(t_hit, d_t.p, n * 4, hipMemcpyDeviceToHost));
+    if (prim) HIP_TRY(hipMemcpy(prim, d_p.p, n * 4, hipMemcpyDeviceToHost));
+    if (bary) HIP_TRY(hipMemcpy(bary, d_b.p, 3 * n * 4, hipMemcpyDeviceToHost));
+    if (occ) HIP_TRY(hipMemcpy(occ, d_occ.p, n, hipMemcpyDeviceToHost));
+    if (out24) HIP_TRY(hipMemcpy(out24, d_o.p, 24 * n * 4, hipMemcpyDeviceToHost));
+    DevStats ds; HIP_TRY(hipMemcpy(&ds, s->stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+    stats_out(ds, st, ms);
+    cleanup();
+    return FTN_OK;
+}
+int ftn_intersect(const ftn_scene* s, const float* rays, size_t n, float* t_hit, int32_t* prim, float* bary, ftn_stats* st) {
+    return trace_batch(s, rays, n, 0, t_hit, prim, bary, nullptr, nullptr, st);
+}
+int ftn_intersect_test(const ftn_scene* s, const float* rays, size_t n, uint8_t* occluded, ftn_stats* st) {
+    return trace_batch(s, rays, n, 1, nullptr, nullptr, nullptr, occluded, nullptr, st);
+}
+int ftn_intersect_full(const ftn_scene* s, const float* rays, size_t n, float* out24) {
+    return trace_batch(s, rays, n, 2, nullptr, nullptr, nullptr, nullptr, out24, nullptr);
+}
+
+/* ------------------------------------------------------------------ render */
+int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn_film_desc* film, const ftn_sampler_desc* sd, const ftn_integrator_desc* id,
+                      const ftn_tile_range* tr, const ftn_render_options* opt, void* device_pixels, void* stream_v, ftn_stats* st) {
+    if (!cs || !cam || !film || !sd || !id || !device_pixels) return fail(FTN_ERR_INVALID_ARGUMENT, "null argument");
+    ftn_scene* s = const_cast<ftn_scene*>(cs);
+    int rc = set_device(opt && opt->device >= 0 ? opt->device : s->device); if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const bool indexed = sd->kind == FTN_SAMPLER_INDEXED;
+    if (!indexed && sd->kind != FTN_SAMPLER_TILE_SERIAL) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown sampler kind");
+    if (!indexed && (sd->first_sample != 0 || (sd->sample_count != 0 && sd->sample_count != sd->samples_per_pixel)))
+        return fail(FTN_ERR_INVALID_ARGUMENT, "sample ranges need FTN_SAMPLER_INDEXED");
+    if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
+    uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
+    if (pipeline == FTN_PIPELINE_AUTO) pipeline = FTN_PIPELINE_MEGAKERNEL;   /* TODO(wavefront): indexed + path -> FTN_PIPELINE_WAVEFRONT */
+    if (pipeline == FTN_PIPELINE_WAVEFRONT && (!indexed || id->kind != FTN_INTEGRATOR_PATH))
+        return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED + FTN_INTEGRATOR_PATH");
+    const bool count = opt && opt->count_traffic;
+
+    std::vector<DTile> all, sel; list_tiles(film, &all);
+    const uint32_t stride = tr && tr->stride ? tr->stride : 1, first = tr ? tr->first : 0, cnt = tr ? tr->count : 0;
+    for (size_t i = first, k = 0; i < all.size() && (cnt == 0 || k < cnt); i += stride, k++) sel.push_back(all[i]);
+
+    RenderParams P; memset(&P, 0, sizeof(P));
+    P.S = s->d;
+    memcpy(P.C.c2w, cam->camera_to_world.m, 64); memcpy(P.C.r2c, cam->raster_to_camera.m, 64);
+    P.C.shutter_open = cam->shutter_open; P.C.shutter_close = cam->shutter_close; P.C.lens_radius = cam->lens_radius; P.C.focal_dist = cam->focal_dist;
+    for (int i = 0; i < 4; i++) P.crop[i] = film->crop[i];
+    P.radius[0] = film->filter_radius[0]; P.radius[1] = film->filter_radius[1]; P.inv_radius[0] = 1.0f / P.radius[0]; P.inv_radius[1] = 1.0f / P.radius[1];
+    P.sampler_kind = sd->kind; P.spp = sd->samples_per_pixel; P.seed = sd->seed;
+    P.first_sample = indexed ? sd->first_sample : 0;
+    P.last_sample = indexed ? sd->first_sample + (sd->sample_count ? sd->sample_count : (sd->samples_per_pixel - sd->first_sample)) : sd->samples_per_pixel;
+    P.integrator_kind = id->kind; P.max_depth = id->max_depth; P.rr_threshold = id->rr_threshold;
+    P.stack_entries = s->stack_entries;
+
+    const size_t npix = (size_t)std::max(0, film->crop[2] - film->crop[0]) * (size_t)std::max(0, film->crop[3] - film->crop[1]);
+    if (npix > s->acc_pixels) {
+        s->accA.release(); s->accB.release(); s->accC.release();
+        HIP_TRY(hipMalloc((void**)&s->accA.p, npix * sizeof(float4))); HIP_TRY(hipMalloc((void**)&s->accB.p, npix * sizeof(float4))); HIP_TRY(hipMalloc((void**)&s->accC.p, npix * sizeof(float4)));
+        s->acc_pixels = npix;
+    }
+    if (sel.size() > s->tiles.n) { s->tiles.release(); HIP_TRY(hipMalloc((void**)&s->tiles.p, sel.size() * sizeof(DTile))); s->tiles.n = sel.size(); }
+    HIP_TRY(hipMemsetAsync(s->accA.p, 0, npix * sizeof(float4), stream));
+    HIP_TRY(hipMemsetAsync(s->accB.p, 0, npix * sizeof(float4), stream));
+    HIP_TRY(hipMemsetAsync(s->accC.p, 0, npix * sizeof(float4), stream));
+    HIP_TRY(hipMemsetAsync(s->stats.p, 0, sizeof(DevStats), stream));
+    if (!sel.empty()) HIP_TRY(hipMemcpyAsync(s->tiles.p, sel.data(), sel.size() * sizeof(DTile), hipMemcpyHostToDevice, stream));
+    P.tiles = s->tiles.p; P.n_tiles = (uint32_t)sel.size();
+    P.accA = s->accA.p; P.accB = s->accB.p; P.accC = s->accC.p; P.stats = s->stats.p;
+
+    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+    WavefrontTimes wt; memset(&wt, 0, sizeof(wt));
+    if (pipeline == FTN_PIPELINE_WAVEFRONT) { rc = wavefront_render(&s->wf, P, sel, count, stream, &wt); if (rc) return fail(rc, wavefront_error()); }
+    else launch_render_mega(P, count, stream);
+    launch_film_resolve(P, (ftn_pixel*)device_pixels, stream);
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DevStats ds; HIP_TRY(hipMemcpy(&ds, s->stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+    stats_out(ds, st, ms);
+    if (st) { st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; }
+    if (ds.error == FTN_ERR_NAN_RADIANCE) return fail(FTN_ERR_NAN_RADIANCE, "NaN radiance value (integrator/mod.rs:285-287)");
+    if (ds.error) return fail(ds.error, "unsupported material / integrator combination (e.g. specular glass: material/glass.rs:66)");
+    return FTN_OK;
+}
+
+int ftn_render(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn_film_desc* film, const ftn_sampler_desc* sd, const ftn_integrator_desc* id,
+               const ftn_tile_range* tr, const ftn_render_options* opt, ftn_pixel* out_pixels, ftn_stats* st) {
+    if (!cs || !film || !out_pixels) return fail(FTN_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(opt && opt->device >= 0 ? opt->device : cs->device); if (rc) return rc;
+    const size_t npix = (size_t)std::max(0, film->crop[2] - film->crop[0]) * (size_t)std::max(0, film->crop[3] - film->crop[1]);
+    DevBuf<ftn_pixel> dev;
+    if ((rc = dev.alloc_zero(npix))) return rc;
+    rc = ftn_render_device(cs, cam, film, sd, id, tr, opt, dev.p, nullptr, st);
+    if (rc == FTN_OK || rc == FTN_ERR_NAN_RADIANCE) {
+        std::vector<ftn_pixel> h(npix);
+        if (hipMemcpy(h.data(), dev.p, npix * sizeof(ftn_pixel), hipMemcpyDeviceToHost) != hipSuccess) { dev.release(); return fail(FTN_ERR_NO_DEVICE, "copy back failed"); }
+        for (size_t i = 0; i < npix; i++) {                                       /* merge_pixel.xyz[i] += xyz[i] (film.rs:127-130) */
+            out_pixels[i].xyz[0] += h[i].xyz[0]; out_pixels[i].xyz[1] += h[i].xyz[1]; out_pixels[i].xyz[2] += h[i].xyz[2];
+            out_pixels[i].filter_weight_sum += h[i].filter_weight_sum;
+        }
+    }
+    dev.release();
+    return rc;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,40 @@
+/*
+ * ftn_kernels.h -- launch parameter blocks shared by the host driver (ftn_host.cpp) and the gfx950 kernels
+ * (ftn_kernels.hip, ftn_wavefront.hip).  Plain data only.
+ */
+#ifndef FTN_KERNELS_H
+#define FTN_KERNELS_H
+
+#include "ftn_device.h"
+
+namespace ftn {
+
+struct DevStats {
+    unsigned long long rays_closest, rays_any, nodes_visited, prims_tested, camera_samples, spill_samples;
+    int error;          /* 0 or an ftn_status (NaN radiance, unsupported material) */
+    int _pad;
+};
+
+struct DTile { int x0, y0, x1, y1; unsigned long long tile_id; };   /* sample-space tile + its sampler seed */
+
+struct RenderParams {
+    DScene S; DCamera C;
+    int crop[4];                      /* cropped_pixel_bounds x0,y0,x1,y1 */
+    float radius[2], inv_radius[2];   /* BoxFilter */
+    uint32_t sampler_kind, spp, first_sample, last_sample;   /* render 0-based samples [first, last) */
+    unsigned long long seed;
+    uint32_t integrator_kind, max_depth; float rr_threshold;
+    const DTile* tiles; uint32_t n_tiles;
+    float4 *accA, *accB, *accC;       /* per crop pixel: rgb sum + weight: own samples / in-tile spill / cross-tile spill */
+    DevStats* stats;
+    uint32_t stack_entries;           /* LDS stack depth per lane */
+};
+
+/* kernels (defined in ftn_kernels.hip) -- host-callable launchers */
+void launch_render_mega(const RenderParams& p, bool count, hipStream_t stream);
+void launch_film_resolve(const RenderParams& p, ftn_pixel* device_pixels, hipStream_t stream);
+void launch_trace_batch(const DScene& S, const float* rays, size_t n, int mode /*0 closest,1 any,2 full*/, float* t_hit, int* prim,
+                        float* bary, unsigned char* occluded, float* out24, DevStats* stats, uint32_t stack_entries, bool count, hipStream_t stream);
+
+}  // namespace ftn
+#endif
