@@ -1,0 +1,135 @@
+"""Host-side constructors of the product (libfountain_hip.so, no GPU needed) against the CPU oracle, bit for bit:
+Transform algebra, Sphere::new, PerspectiveCamera::new, Film::new / sample_bounds / tiles, BVH::build."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fountain_amd import Film, PerspectiveCamera, SceneBuilder, Transform, _abi as A, scenes
+
+
+def raw(x):
+    return bytes(x)
+
+
+def chain(be, rng_seed):
+    rng = np.random.default_rng(rng_seed)
+    t = Transform.identity(be)
+    for _ in range(6):
+        k = rng.integers(0, 4)
+        if k == 0:
+            t = t * Transform.translate(be, rng.uniform(-5, 5, 3))
+        elif k == 1:
+            t = t * Transform.scale(be, *rng.uniform(0.3, 3, 3))
+        elif k == 2:
+            t = t * Transform.rotate(be, float(rng.uniform(0, 360)), rng.normal(size=3))
+        else:
+            t = t * Transform.look_at(be, rng.uniform(-5, 5, 3), rng.uniform(-5, 5, 3), (0, 0, 1))
+    return t
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_transform_algebra(ftn, orc_det, seed):
+    a, b = chain(ftn, seed), chain(orc_det, seed)
+    assert raw(a.raw) == raw(b.raw)
+    m = a.matrix().astype(np.float64)
+    inv = np.array(a.raw.inv[:], np.float32).reshape(4, 4).T.astype(np.float64)
+    assert np.allclose(m @ inv, np.eye(4), atol=2e-3)             # cgmath cofactor inverse really inverts
+    p = np.float32([0.3, -1.2, 2.5])
+    for fn in ("point", "vector", "normal"):
+        assert np.array_equal(getattr(a, fn)(p), getattr(b, fn)(p))
+    assert a.swaps_handedness() == b.swaps_handedness()
+    pts = np.random.default_rng(seed).normal(size=(100, 3)).astype(np.float32)
+    assert np.array_equal(a.points(pts), b.points(pts)) and np.array_equal(a.normals(pts), b.normals(pts))
+
+
+def test_perspective_and_camera(ftn, orc_det):
+    for fov, res, lens in ((60.0, (16, 16), 0.0), (40.0, (1920, 1080), 0.05), (90.0, (64, 48), 0.0)):
+        pa, pb = Transform.perspective(ftn, fov, 1e-2, 1000.0), Transform.perspective(orc_det, fov, 1e-2, 1000.0)
+        assert raw(pa.raw) == raw(pb.raw)
+        ca = PerspectiveCamera.look_at(ftn, (3, -4, 2), (0, 0, 0), (0, 0, 1), res, fov=fov, lens_radius=lens, focal_dist=5.0)
+        cb = PerspectiveCamera.look_at(orc_det, (3, -4, 2), (0, 0, 0), (0, 0, 1), res, fov=fov, lens_radius=lens, focal_dist=5.0)
+        assert raw(ca.desc) == raw(cb.desc)
+
+
+def test_film_bounds_and_tiles(ftn, orc_det):
+    for res, crop in (((16, 16), (0, 0, 1, 1)), ((1920, 1080), (0, 0, 1, 1)), ((100, 60), (0.25, 0.1, 0.75, 0.9)), ((4096, 4096), (0, 0, 1, 1))):
+        fa, fb = Film(ftn, res, crop), Film(orc_det, res, crop)
+        assert raw(fa.desc) == raw(fb.desc)
+        assert fa.sample_bounds() == fb.sample_bounds() and fa.tile_count() == fb.tile_count()
+    assert Film(ftn, (1920, 1080)).tile_count() == 120 * 68
+    assert Film(ftn, (4096, 4096)).tile_count() == 65536
+
+
+def test_sphere_init(ftn, orc_det):
+    for args in ((1.0, -1.0, 1.0, 360.0), (100.0, -100.0, 100.0, 360.0), (2.0, -0.5, 1.5, 270.0)):
+        out = []
+        for be in (ftn, orc_det):
+            t = Transform.translate(be, (1, 2, 3)) * Transform.scale(be, 1, 1, 1)
+            s = A.ftn_sphere()
+            be.call("sphere_init", C.byref(t.raw), C.byref(t.inverse().raw), 1, *args, C.byref(s))
+            out.append(raw(s))
+        assert out[0] == out[1]
+
+
+def bvh_of(ftn, builder):
+    d, keep = builder.build_desc()
+    nodes = np.zeros(max(2 * d.n_prims, 1), dtype=scenes_node_dtype())
+    order = np.zeros(max(d.n_prims, 1), np.uint32)
+    nn, md = C.c_uint32(), C.c_uint32()
+    ftn.call("bvh_build", C.byref(d), nodes.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), C.byref(nn), C.byref(md))
+    return nodes[:nn.value], order[:d.n_prims], md.value
+
+
+def scenes_node_dtype():
+    from fountain_amd.api import NODE_DTYPE
+    return NODE_DTYPE
+
+
+@pytest.mark.parametrize("which", ["cornell", "cube", "cubes27", "spheres"])
+def test_bvh_build_matches_oracle(ftn, orc_det, which):
+    """BVH::build (bvh.rs:27-158): identical LinearBVHNode array, primitive permutation and depth."""
+    def make(be):
+        if which == "cornell":
+            return scenes.cornell(be, res=16)[0]
+        if which == "cube":
+            return scenes.rounded_cube_env(be, res=16, env_n=4)[0]
+        if which == "cubes27":
+            return scenes.instanced_cubes(be, n_copies=27, res=(16, 16), env_n=4)[0]
+        b = SceneBuilder(be)
+        rng = np.random.default_rng(1)
+        for c in rng.uniform(-10, 10, (200, 3)):
+            b.attribute_begin(); b.translate(c); b.shape("sphere", radius=float(rng.uniform(0.2, 2))); b.attribute_end()
+        return b
+    nodes, order, depth = bvh_of(ftn, make(ftn))
+    osc = make(orc_det).create_scene()
+    onodes, oorder = osc.nodes()
+    assert np.array_equal(nodes.view(np.uint8), onodes.view(np.uint8))
+    assert np.array_equal(order, oorder)
+    assert depth == osc.info()["max_depth"]
+    leaves = nodes[nodes["is_leaf"] == 1]
+    assert leaves["n_prims"].sum() == len(order) and len(nodes) == 2 * len(leaves) - 1
+
+
+def test_empty_and_single_primitive_scenes(ftn):
+    b = SceneBuilder(ftn)
+    nodes, order, depth = bvh_of(ftn, b)
+    assert len(nodes) == 0 and len(order) == 0
+    b.shape("sphere", radius=1.0)
+    nodes, order, depth = bvh_of(ftn, b)
+    assert len(nodes) == 1 and nodes[0]["is_leaf"] == 1 and depth == 0
+
+
+def test_invalid_descriptions_are_rejected(ftn):
+    from fountain_amd import FountainError
+    b = SceneBuilder(ftn)
+    b.shape("trianglemesh", P=[(0, 0, 0), (1, 0, 0), (0, 1, 0)], indices=[0, 1, 7])
+    with pytest.raises(FountainError) as e:
+        bvh_of(ftn, b)
+    assert e.value.code == A.FTN_ERR_INVALID_ARGUMENT
+    b = SceneBuilder(ftn)
+    b.light_source("infinite", texels=np.ones((3, 3, 3), np.float32))      # not a power of two
+    b.shape("sphere", radius=1.0)
+    with pytest.raises(FountainError) as e:
+        bvh_of(ftn, b)
+    assert e.value.code == A.FTN_ERR_UNSUPPORTED
