@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary) of the wavefront path tracer on the 10M-triangle synthetic scene
+(BASELINE.json config 5: 2309 baked copies of rounded_cube, 4096x4096 film, PathIntegrator(5, 1.0), env-map light).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+A STEP is one pass of the hot path over one batch of camera samples: N samples per pixel of the 4096x4096 film, with the
+film's 65,536 tiles interleaved over the N ranks -- so every GPU traces the same number of paths per step whatever N is
+(weak scaling of the 4096-spp job; `value` is the whole-job rate).  The film stays resident in HBM (a torch tensor handed to
+ftn_render_device by pointer); at the end of the timed region the ranks' films are summed by ONE RCCL reduce.
+Prints one JSON line on rank 0."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--copies", type=int, default=int(os.environ.get("FTN_BENCH_COPIES", "2309")), help="mesh copies (2309 = 10,002,588 triangles)")
+    ap.add_argument("--res", type=int, default=int(os.environ.get("FTN_BENCH_RES", "4096")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=int(os.environ.get("FTN_BENCH_CPU_TILES", "96")))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fountain_amd import Film, PathIntegrator, RandomSampler, SamplerIntegrator, default_backend, scenes, _abi as A
+    from fountain_amd.distributed import merge_film, tile_shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    gpu = default_backend()
+
+    # ---- scene (host assembly + BVH::build + upload; not timed: SURVEY 8(d))
+    t0 = time.time()
+    builder, cam, res = scenes.instanced_cubes(gpu, n_copies=args.copies, res=(args.res, args.res))
+    desc, keep = builder.build_desc()
+    from fountain_amd.api import Scene
+    scene = Scene(gpu, desc, keep, device=local_rank)
+    info = scene.info()
+    build_s = time.time() - t0
+    film = Film(gpu, res)
+    n_tiles = film.tile_count()
+    tiles = tile_shard(rank, world)
+    integ = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    dev_film = torch.zeros((film.height, film.width, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    spp_per_step = world
+    total_spp = 4096
+
+    def step(i, count=False):
+        smp = RandomSampler(total_spp, 0, indexed=True, first_sample=(i * spp_per_step) % total_spp, sample_count=spp_per_step)
+        return integ.render_device(scene, film, smp, dev_film.data_ptr(), stream.cuda_stream, tiles=tiles,
+                                   pipeline=A.FTN_PIPELINE_WAVEFRONT, device=local_rank, count_traffic=count)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # one counted step: algorithmic bytes of the dominant kernel (nodes / triangles per ray are data dependent: SURVEY 8(d))
+    cst = step(0, count=True)
+    dev_film.zero_()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    rays = 0
+    trace_ms = 0.0
+    trace_launches = 0
+    kernel_ms = 0.0
+    cam_samples = 0
+    for i in range(args.steps):
+        st = step(args.warmup + i)
+        rays += st["rays_closest"] + st["rays_any"]
+        trace_ms += st["trace_ms"]
+        trace_launches += st["trace_launches"]
+        kernel_ms += st["kernel_ms"]
+        cam_samples += st["camera_samples"]
+    merge_film(dev_film)                      # the single end-of-frame reduce (RCCL over xGMI)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays), float(cam_samples)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays, cam_samples = int(t[1]), int(t[2])
+
+    if rank == 0:
+        mrays = rays / elapsed / 1e6
+        # ---- roofline of the dominant kernel, k_wf_trace<closest>: algorithmic bytes / its launches' device time
+        nodes_c = cst["nodes_visited"] - cst["nodes_visited_any"]
+        prims_c = cst["prims_tested"] - cst["prims_tested_any"]
+        bytes_per_step = 32.0 * nodes_c + 48.0 * prims_c + (32.0 + 16.0) * cst["rays_closest"]
+        launches_per_step = max(cst["trace_launches"], 1)
+        bytes_per_launch = bytes_per_step / launches_per_step
+        avg_launch_ms = trace_ms / max(trace_launches, 1)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary+secondary) at fixed spp", "value": round(mrays, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 5 scene: %d baked copies of rounded_cube = %d triangles (%d BVH nodes, depth %d), %dx%d film, "
+                                   "PathIntegrator(max_depth 5, rr 1.0), 1024^2 env-map light; one step = %d spp over the whole film"
+                                   % (args.copies, info["n_prims"], info["n_nodes"], info["max_depth"], res[0], res[1], spp_per_step),
+                       "tiles": n_tiles, "tiles_per_gpu": (n_tiles + world - 1) // world, "camera_samples_per_step": cam_samples // max(args.steps, 1),
+                       "rays_per_step": rays // max(args.steps, 1), "pipeline": "wavefront", "sampler": "indexed xoshiro256+",
+                       "scene_build_s": round(build_s, 1), "device_ms_per_step": round(kernel_ms / max(args.steps, 1), 3)},
+            "roofline": {"bound": "hbm", "kernel": "k_wf_trace<closest>", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
+                         "launches_per_step": int(launches_per_step), "nodes_per_ray": round(nodes_c / max(cst["rays_closest"], 1), 2),
+                         "prims_per_ray": round(prims_c / max(cst["rays_closest"], 1), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, cam, film, args.cpu_tiles, n_tiles)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(desc, cam, film, n_cpu_tiles, n_tiles):
+    """The CPU oracle (a C++ restatement of fountain's CPU path, NOT fountain itself: no Rust toolchain here) timed on a
+    bounded sample of the same workload: n_cpu_tiles tiles spread evenly over the film, 1 spp, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_loader import oracle_backend
+    from fountain_amd import PathIntegrator, RandomSampler, SamplerIntegrator, Film
+    from fountain_amd.api import Scene
+    orc = oracle_backend(det=False)
+    t0 = time.time()
+    scene = Scene(orc, desc, None)
+    build_s = time.time() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("FTN_BENCH_CPU_THREADS", "64"))))
+    f = Film(orc, (film.desc.full_resolution[0], film.desc.full_resolution[1]))
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    smp = RandomSampler(4096, 0, indexed=True, first_sample=0, sample_count=1)
+    # calibrate on a few tiles, then size the sample for ~15 s of wall time
+    probe = max(cores, 16)
+    stride = max(1, n_tiles // probe)
+    st = si.render_parallel(scene, f, smp, tiles=(stride // 2, stride, probe), n_threads=cores)
+    rate = probe / max(st["kernel_ms"] * 1e-3, 1e-3)
+    n_cpu_tiles = int(min(n_tiles, max(n_cpu_tiles, rate * 15.0)))
+    stride = max(1, n_tiles // n_cpu_tiles)
+    f = Film(orc, (film.desc.full_resolution[0], film.desc.full_resolution[1]))
+    st = si.render_parallel(scene, f, smp, tiles=(stride // 2, stride, n_cpu_tiles), n_threads=cores)
+    rays = st["rays_closest"] + st["rays_any"]
+    secs = st["kernel_ms"] * 1e-3
+    return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d tiles (every %dth), 1 spp, same scene/integrator; %.1f s of wall time on %d threads; C++ restatement of fountain's CPU path "
+                      "(oracle/), transcendentals from libm; oracle BVH build %.0f s not counted" % (n_cpu_tiles, n_tiles, stride, secs, cores, build_s)}
+
+
+if __name__ == "__main__":
+    main()

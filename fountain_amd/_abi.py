@@ -112,7 +112,8 @@ class ftn_render_options(C.Structure):
 class ftn_stats(C.Structure):
     _fields_ = [("rays_closest", c_u64), ("rays_any", c_u64), ("nodes_visited", c_u64), ("prims_tested", c_u64),
                 ("camera_samples", c_u64), ("spill_samples", c_u64), ("kernel_ms", C.c_double),
-                ("trace_ms", C.c_double), ("trace_launches", c_u64), ("reserved", c_u64 * 3)]
+                ("trace_ms", C.c_double), ("trace_launches", c_u64), ("nodes_visited_any", c_u64),
+                ("prims_tested_any", c_u64), ("reserved", c_u64 * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -136,5 +137,5 @@ DECLARED_FUNCTIONS = [
     "ftn_film_sample_bounds", "ftn_film_tile_count", "ftn_film_resolve", "ftn_scene_create",
     "ftn_scene_destroy", "ftn_bvh_build", "ftn_scene_info", "ftn_scene_get_nodes", "ftn_scene_get_lights",
     "ftn_intersect", "ftn_intersect_test", "ftn_intersect_full", "ftn_render", "ftn_render_device",
-    "ftn_last_error", "ftn_device_count", "ftn_version",
+    "ftn_last_error", "ftn_device_count", "ftn_version", "ftn_test_math",
 ]

@@ -418,17 +418,19 @@ class SceneBuilder:
     def build_desc(self):
         """Flatten into an ftn_scene_desc; returns (desc, keepalive)."""
         keep = []
-        prims = []
+        chunks = []
         for p in self.prims:
             if p[0] == "trirange":
                 _, first, nt, mat, area = p
-                for k in range(nt):
-                    prims.append((A.FTN_SHAPE_TRIANGLE, first + k, mat, area))
+                c = np.empty(nt, dtype=PRIM_DTYPE)
+                c["k"] = A.FTN_SHAPE_TRIANGLE
+                c["i"] = np.arange(first, first + nt, dtype=np.uint32)
+                c["m"] = mat
+                c["a"] = area
             else:
-                prims.append(p)
-        parr = np.array(prims, dtype=np.int64).reshape(-1, 4) if prims else np.zeros((0, 4), np.int64)
-        pa = np.zeros(parr.shape[0], dtype=[("k", "<u4"), ("i", "<u4"), ("m", "<i4"), ("a", "<i4")])
-        pa["k"], pa["i"], pa["m"], pa["a"] = parr[:, 0], parr[:, 1], parr[:, 2], parr[:, 3]
+                c = np.array([p], dtype=PRIM_DTYPE)
+            chunks.append(c)
+        pa = np.ascontiguousarray(np.concatenate(chunks)) if chunks else np.zeros(0, dtype=PRIM_DTYPE)
         d = A.ftn_scene_desc()
         d.n_prims = pa.shape[0]
         d.prims = pa.ctypes.data_as(C.POINTER(A.ftn_prim))
@@ -548,6 +550,7 @@ class Scene:
         return out
 
 
+PRIM_DTYPE = np.dtype([("k", "<u4"), ("i", "<u4"), ("m", "<i4"), ("a", "<i4")])
 NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("idx", "<u4"), ("n_prims", "<u2"), ("axis", "u1"), ("is_leaf", "u1")])
 
 

@@ -540,6 +540,7 @@ static void stats_out(const DevStats& ds, ftn_stats* st, double ms) {
     memset(st, 0, sizeof(*st));
     st->rays_closest = ds.rays_closest; st->rays_any = ds.rays_any; st->nodes_visited = ds.nodes_visited; st->prims_tested = ds.prims_tested;
     st->camera_samples = ds.camera_samples; st->spill_samples = ds.spill_samples; st->kernel_ms = ms;
+    st->nodes_visited_any = ds.nodes_any; st->prims_tested_any = ds.prims_any;
 }
 static int trace_batch(const ftn_scene* cs, const float* rays, size_t n, int mode, float* t_hit, int32_t* prim, float* bary, uint8_t* occ, float* out24, ftn_stats* st) {
     ftn_scene* s = const_cast<ftn_scene*>(cs);
@@ -591,7 +592,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
         return fail(FTN_ERR_INVALID_ARGUMENT, "sample ranges need FTN_SAMPLER_INDEXED");
     if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
     uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
-    if (pipeline == FTN_PIPELINE_AUTO) pipeline = FTN_PIPELINE_MEGAKERNEL;   /* TODO(wavefront): indexed + path -> FTN_PIPELINE_WAVEFRONT */
+    if (pipeline == FTN_PIPELINE_AUTO) pipeline = (indexed && id->kind == FTN_INTEGRATOR_PATH) ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
     if (pipeline == FTN_PIPELINE_WAVEFRONT && (!indexed || id->kind != FTN_INTEGRATOR_PATH))
         return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED + FTN_INTEGRATOR_PATH");
     const bool count = opt && opt->count_traffic;
@@ -642,6 +643,17 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     if (st) { st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; }
     if (ds.error == FTN_ERR_NAN_RADIANCE) return fail(FTN_ERR_NAN_RADIANCE, "NaN radiance value (integrator/mod.rs:285-287)");
     if (ds.error) return fail(ds.error, "unsupported material / integrator combination (e.g. specular glass: material/glass.rs:66)");
+    return FTN_OK;
+}
+
+int ftn_test_math(int which, const float* x, const float* y, size_t n, float* out) {
+    int rc = set_device(-1); if (rc) return rc;
+    DevBuf<float> dx, dy, dout;
+    if ((rc = dx.upload(x, n)) || (rc = dy.upload(y, n)) || (rc = dout.alloc_zero(n))) { dx.release(); dy.release(); dout.release(); return rc; }
+    launch_test_math(which, dx.p, dy.p, n, dout.p, 0);
+    hipError_t e = hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost);
+    dx.release(); dy.release(); dout.release();
+    if (e != hipSuccess) return fail(FTN_ERR_NO_DEVICE, hipGetErrorString(e));
     return FTN_OK;
 }
 

@@ -390,4 +390,22 @@ void launch_trace_batch(const DScene& S, const float* rays, size_t n, int mode, 
 #undef FTN_LAUNCH
 }
 
+/* ------------------------------------------------------------------ test hook: device evaluation of the scalar math */
+FTN_HD float eval_math(int which, float x, float y) {
+    switch (which) {
+        case 0: return ftn_det::sinf_det(x); case 1: return ftn_det::cosf_det(x); case 2: return ftn_det::tanf_det(x);
+        case 3: return ftn_det::acosf_det(x); case 4: return ftn_det::atanf_det(x); case 5: return ftn_det::atan2f_det(x, y);
+        case 6: return ftn_det::logf_det(x); case 7: return ftn_det::log2f_det(x); case 8: return sqrtf(x); case 9: return x / y;
+        case 10: return (float)sqrt((double)x * (double)y); case 11: return next_up(x); case 12: return next_down(x);
+        default: return 0.0f;
+    }
+}
+__global__ void k_test_math(int which, const float* x, const float* y, size_t n, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = eval_math(which, x[i], y[i]);
+}
+void launch_test_math(int which, const float* x, const float* y, size_t n, float* out, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_test_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, which, x, y, n, out);
+}
+
 }  // namespace ftn

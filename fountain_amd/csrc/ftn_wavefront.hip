@@ -1,7 +1,517 @@
+/*
+ * ftn_wavefront.hip -- wavefront restructuring of PathIntegrator::incident_radiance (src/integrator/path.rs:25-95) for gfx950.
+ *
+ * The reference walks one path at a time: intersect -> emission -> NEE (shadow ray + MIS ray) -> BSDF sample -> RR -> loop.
+ * Here a PASS renders S samples of every owned pixel at once; paths live as float4 SoA records in HBM and every bounce runs
+ * three kernels over queues of path ids:
+ *
+ *   k_wf_generate   get_camera_sample + generate_ray (sampler/mod.rs:43-51, camera/mod.rs:145-205); all paths -> closest queue
+ *   k_wf_trace<ANY> Scene::intersect / intersect_test (bvh.rs:160-266) for a queue of rays.  Persistent 256-thread
+ *                   workgroups; each wave64 pulls rays from the queue with ONE atomic per refill (__ballot / __popcll /
+ *                   __shfl): lanes whose ray finished are re-armed while the others keep walking, so a wave stays full
+ *                   until the queue is drained.  Per-lane node stack in LDS, [level][lane] interleaved.
+ *   k_wf_shade      everything between two intersect calls of the Li loop: resolves the previous bounce's direct lighting
+ *                   (shadow + MIS results), emission, termination, Material -> Bsdf, uniform_sample_one_light /
+ *                   estimate_direct set-up, BSDF sampling, Russian roulette; emits shadow / MIS / continuation rays and
+ *                   compacts the surviving paths into the next queue (ballot + one atomic per wave).
+ *   k_wf_accumulate Film::add_sample_to_tile for the pass's samples of each pixel IN SAMPLE ORDER (film.rs:136-172).
+ *
+ * All per-path arithmetic and the order of the RNG draws are those of the reference (and of the megakernel), so both
+ * pipelines produce identical radiance.  Dominant kernel: k_wf_trace<false>; roofline = HBM (node + triangle fetches).
+ */
 #include "ftn_wavefront.h"
+#include <string>
+
 namespace ftn {
-struct WavefrontState { int unused; };
-int wavefront_render(WavefrontState**, const RenderParams&, const std::vector<DTile>&, bool, hipStream_t, WavefrontTimes*) { return FTN_ERR_UNSUPPORTED; }
-void wavefront_destroy(WavefrontState* s) { delete s; }
-const char* wavefront_error() { return "wavefront pipeline not built yet"; }
+
+/* pstate bits */
+enum : uint32_t { PS_BOUNCE_MASK = 0xffu, PS_SPECULAR = 1u << 8, PS_ALIVE = 1u << 9, PS_DIRECT = 1u << 10, PS_SHADOW = 1u << 11, PS_MIS = 1u << 12, PS_DELTA = 1u << 13 };
+#define WF_MIS_BIT 0x80000000u
+
+struct WfBuffers {
+    uint32_t n_paths;           /* S * n_slots */
+    uint32_t n_slots;           /* tiles * 256 */
+    uint32_t samples;           /* S */
+    uint32_t first_sample;      /* 0-based index of this pass's first sample */
+    /* rays / hits: index r in [0, n_paths) = continuation ray of path r, [n_paths, 2 n_paths) = MIS ray of path r - n_paths */
+    float4 *ray_o, *ray_d;      /* xyz (+ unused, t_max) */
+    float4* hit;                /* t, b0, b1, b2 */
+    int* hit_prim;
+    float4 *sh_o, *sh_d;        /* shadow rays, per path */
+    unsigned char* occluded;    /* per path */
+    float4 *beta;               /* beta.xyz, bits(pstate) */
+    float4 *rad;                /* L.xyz, bits(light index of the pending direct term) */
+    ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
+    float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
+    uint32_t *q_active[2], *q_closest, *q_shadow;
+    uint32_t* counters;         /* [0] active_in [1] active_out [2] closest [3] shadow [4] head_closest [5] head_shadow */
+};
+
+__device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
+/* wave-level queue append: one atomic per wave (ballot / popc compaction) */
+__device__ inline void wave_push(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = value;
 }
+
+/* ------------------------------------------------------------------ generate */
+__global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;          /* path id = s * n_slots + slot */
+    if (i >= W.n_paths) return;
+    const uint32_t slot = i % W.n_slots, s = i / W.n_slots;
+    const DTile tile = P.tiles[slot >> 8];
+    const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
+    const bool valid = px < tile.x1 && py < tile.y1;
+    if (valid) {
+        Rng rng; rng.seed(indexed_key(P.seed, px, py, W.first_sample + s));
+        V2 j = rng.next2();
+        V2 p_film((float)px + j.x, (float)py + j.y);
+        V2 p_lens = rng.next2();
+        float time_u = rng.next();
+        DRay ray = camera_ray(P.C, p_film, p_lens, time_u);
+        W.ray_o[i] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+        W.ray_d[i] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.t_max);
+        W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
+        W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
+    }
+    /* slots are dense per tile; invalid (clipped) lanes simply never enter a queue */
+    wave_push(valid, i, W.q_active[0], &W.counters[0]);
+    wave_push(valid, i, W.q_closest, &W.counters[2]);
+}
+
+/* ------------------------------------------------------------------ trace */
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
+                                                  DevStats* stats, uint32_t refill_below) {
+    extern __shared__ uint32_t lds_stack[];
+    const LdsStack st{lds_stack + threadIdx.x, 256u};
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = lane_id();
+    const uint32_t np = W.n_paths;
+    TravCount tc{0, 0};
+    bool active = false, exhausted = false;
+    uint32_t rid = 0, cur = 0, neg = 0; int sp = 0;
+    V3 o, d, inv; float t_max = 0.0f; DHit h; bool found = false;
+    for (;;) {
+        const unsigned long long need = __ballot(!active);
+        if (need != 0 && !exhausted) {
+            const int leader = __ffsll((long long)need) - 1;
+            const uint32_t n = (uint32_t)__popcll(need);
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(head, n);
+            base = __shfl(base, leader, 64);
+            if (base + n >= count) exhausted = true;
+            const uint32_t my = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!active && my < count) {
+                rid = queue[my];
+                const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
+                const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
+                o = V3(a.x, a.y, a.z); d = V3(b.x, b.y, b.z); t_max = b.w;
+                inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+                sp = 0; cur = 0; found = false; active = S.n_nodes != 0;
+                h.t = FTN_INF; h.prim = -1; h.b0 = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
+                if (!active) {   /* empty scene: immediate miss */
+                    if (ANY) W.occluded[rid] = 0; else { W.hit[r] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[r] = -1; }
+                }
+            }
+        }
+        if (__ballot(active) == 0) { if (exhausted) break; else continue; }
+        /* walk until too few lanes are left (then refill), or to completion once the queue is drained */
+        for (;;) {
+            if (active) {
+                const float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
+                if (COUNT) tc.nodes++;
+                bool pop = true, done = false;
+                if (slab_test(nlo, nhi, o, inv, t_max)) {
+                    const uint32_t idx = __float_as_uint(nlo.w), meta = __float_as_uint(nhi.w);
+                    if (meta >> 24) {
+                        const uint32_t n = meta & 0xffffu;
+                        for (uint32_t k = 0; k < n; k++) {
+                            const uint32_t prim = idx + k;
+                            const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                            if (COUNT) tc.prims++;
+                            const uint32_t fl = __float_as_uint(g0.w);
+                            float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh;
+                            if (fl & GF_KIND_SPHERE) { DRay r; r.o = o; r.d = d; r.t_max = t_max; r.time = 0.0f; hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr); }
+                            else {
+                                V3 p0(g0.x, g0.y, g0.z), p1(g1.x, g1.y, g1.z), p2(g2.x, g2.y, g2.z);
+                                hh = tri_hit(o, d, t_max, p0, p1, p2, &t, &b0, &b1, &b2);
+                                if (hh && (fl & GF_HAS_UVS) && tri_uv_degenerate_reject(S, (int)prim, p0, p1, p2)) hh = false;
+                            }
+                            if (hh) {
+                                found = true;
+                                if (ANY) { done = true; break; }
+                                t_max = t; h.t = t; h.prim = (int)prim; h.b0 = b0; h.b1 = b1; h.b2 = b2;
+                            }
+                        }
+                    } else {
+                        const uint32_t axis = (meta >> 16) & 3u;
+                        if ((neg >> axis) & 1u) { st.push(sp++, cur + 1); cur = idx; }
+                        else { st.push(sp++, idx); cur = cur + 1; }
+                        pop = false;
+                    }
+                }
+                if (pop && !done) { if (sp == 0) done = true; else cur = st.pop(--sp); }
+                if (done) {
+                    if (ANY) W.occluded[rid] = found ? 1 : 0;
+                    else {
+                        const uint32_t r = (rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid;
+                        W.hit[r] = make_float4(h.t, h.b0, h.b1, h.b2); W.hit_prim[r] = h.prim;
+                    }
+                    active = false;
+                }
+            }
+            const uint32_t alive = (uint32_t)__popcll(__ballot(active));
+            if (alive == 0 || (!exhausted && alive < refill_below)) break;
+        }
+    }
+    if (COUNT) {
+        unsigned long long n = tc.nodes, p = tc.prims;
+        for (int off = 32; off > 0; off >>= 1) { n += __shfl_down(n, off, 64); p += __shfl_down(p, off, 64); }
+        if (lane == 0) {
+            if (n) atomicAdd(&stats->nodes_visited, n); if (p) atomicAdd(&stats->prims_tested, p);
+            if (ANY) { if (n) atomicAdd(&stats->nodes_any, n); if (p) atomicAdd(&stats->prims_any, p); }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
+}
+
+/* ------------------------------------------------------------------ shade */
+__device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
+    const float4 h = W.hit[r]; DHit o; o.t = h.x; o.b0 = h.y; o.b1 = h.z; o.b2 = h.w; o.prim = W.hit_prim[r]; return o;
+}
+
+__global__ void __launch_bounds__(256) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
+    const DScene& S = P.S;
+    const uint32_t count = W.counters[in_q == 0 ? 0 : 1];
+    uint32_t* out_q = W.q_active[in_q ^ 1];
+    uint32_t* out_count = &W.counters[in_q == 0 ? 1 : 0];
+    int err = 0;
+    const uint32_t stride = gridDim.x * 256u;
+    const uint32_t rounds = (count + stride - 1) / stride;
+    for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t qi = round * stride + blockIdx.x * 256u + threadIdx.x;
+        const bool have = qi < count;
+        bool push_active = false, push_closest = false, push_mis = false, push_shadow = false;
+        uint32_t p = 0;
+        if (have) {
+            p = W.q_active[in_q][qi];
+            float4 bq = W.beta[p], lq = W.rad[p];
+            Rgb beta(bq.x, bq.y, bq.z), L(lq.x, lq.y, lq.z);
+            uint32_t ps = __float_as_uint(bq.w);
+            /* ---- finish the previous bounce's estimate_direct (integrator/mod.rs:330-392) */
+            if (ps & PS_DIRECT) {
+                const float4 q0 = W.pend0[p], q1 = W.pend1[p], q2 = W.pend2[p];
+                Rgb radiance(0.0f);
+                if ((ps & PS_SHADOW) && !W.occluded[p]) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
+                if (ps & PS_MIS) {
+                    const int light_index = (int)__float_as_uint(lq.w);
+                    const DLight& Lt = S.lights[light_index];
+                    const DHit mh = load_hit(W, p + W.n_paths);
+                    const float4 mo = W.ray_o[p + W.n_paths], md = W.ray_d[p + W.n_paths];
+                    Rgb inc(0.0f);
+                    if (mh.prim >= 0) {
+                        const uint4 pi = S.prim_info[2 * mh.prim];
+                        if ((int)pi.y >= 0 && (int)pi.y == light_index) {
+                            DRay r0; r0.o = V3(mo.x, mo.y, mo.z); r0.d = V3(md.x, md.y, md.z); r0.t_max = FTN_INF; r0.time = 0.0f;
+                            DSI s2; make_interaction(S, mh, r0, &s2);
+                            inc = area_Le(Lt, s2.hit.n, -r0.d);
+                        }
+                    } else if (Lt.kind == LK_INFINITE) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
+                    if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
+                }
+                Rgb direct = Rgb(q2.x, q2.y, q2.z) * ((float)S.n_lights * radiance);
+                L = L + direct;
+                ps &= ~(PS_DIRECT | PS_SHADOW | PS_MIS);
+            }
+            if (!(ps & PS_ALIVE)) {
+                W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);     /* path finished: final radiance */
+                W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));
+            } else {
+                const float4 ro = W.ray_o[p], rdv = W.ray_d[p];
+                DRay ray0; ray0.o = V3(ro.x, ro.y, ro.z); ray0.d = V3(rdv.x, rdv.y, rdv.z); ray0.t_max = rdv.w; ray0.time = 0.0f;
+                const DHit h = load_hit(W, p);
+                const bool hit = h.prim >= 0;
+                uint32_t bounces = ps & PS_BOUNCE_MASK;
+                const bool specular_bounce = (ps & PS_SPECULAR) != 0;
+                DSI si;
+                if (hit) make_interaction(S, h, ray0, &si);
+                if (bounces == 0 || specular_bounce) {
+                    if (hit) { const uint4 pi = S.prim_info[2 * si.prim]; Rgb e = ((int)pi.y < 0) ? Rgb(0.0f) : area_Le(S.lights[pi.y], si.hit.n, -ray0.d); L = L + beta * e; }
+                    else L = L + beta * scene_env_Le(S, ray0.d);
+                }
+                bool alive = true;
+                uint32_t light_word = 0;
+                if (!hit || bounces >= P.max_depth) alive = false;
+                else {
+                    Rng rng; { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
+                    const int mat = (int)S.prim_info[2 * si.prim].x;
+                    if (mat < 0) {
+                        DRay nr = spawn_ray(si.hit, ray0.d);                       /* null bsdf: path.rs:77-81 */
+                        W.ray_o[p] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray_d[p] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
+                        push_closest = true;
+                    } else {
+                        DBsdf B;
+                        if (!make_bsdf(S.materials[mat], si, true, &B)) { err = FTN_ERR_UNSUPPORTED; alive = false; }
+                        else {
+                            if (bsdf_num(B, T_ALL & ~T_SPECULAR) > 0 && S.n_lights > 0) {
+                                /* uniform_sample_one_light + first half of estimate_direct (integrator/mod.rs:289-329) */
+                                const uint32_t nl = S.n_lights;
+                                const uint32_t ln = (uint32_t)f2usize(fmin_(rng.next() * (float)nl, (float)(nl - 1)));
+                                const V2 ul = rng.next2(), us = rng.next2();
+                                const DLight& Lt = S.lights[ln];
+                                const uint32_t flags = T_ALL & ~T_SPECULAR;
+                                const bool delta = Lt.kind == LK_POINT || Lt.kind == LK_DISTANT;
+                                ps |= PS_DIRECT; light_word = ln;
+                                Rgb ld(0.0f); float mis_w = 0.0f, mis_pdf = 1.0f; Rgb mis_f(0.0f);
+                                DLiSample ls = light_sample(S, Lt, si.hit, ul);
+                                if (ls.pdf > 0.0f && !ls.radiance.is_black()) {
+                                    Rgb f = bsdf_f(B, si.wo, ls.wi, flags) * abs_dot(ls.wi, si.shading_n);
+                                    float sp = bsdf_pdf(B, si.wo, ls.wi, flags);
+                                    if (!f.is_black()) {
+                                        DRay sr = spawn_ray_to_hit(si.hit, ls.p1);
+                                        W.sh_o[p] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f); W.sh_d[p] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.t_max);
+                                        ld = delta ? (f * ls.radiance / ls.pdf) : (f * ls.radiance * power_heuristic(ls.pdf, sp) / ls.pdf);
+                                        ps |= PS_SHADOW; push_shadow = true;
+                                    }
+                                }
+                                if (!delta) {
+                                    DScatter sc;
+                                    if (bsdf_sample(B, si.wo, us, flags, &sc)) {
+                                        Rgb f = sc.f * abs_dot(sc.wi, si.shading_n);
+                                        if (!f.is_black()) {
+                                            bool go = true;
+                                            if (sc.type & T_SPECULAR) mis_w = 1.0f;
+                                            else {
+                                                float lp = light_pdf(S, Lt, si.hit, sc.wi);
+                                                if (lp == 0.0f) go = false; else mis_w = power_heuristic(sc.pdf, lp);
+                                            }
+                                            if (go) {
+                                                DRay mr = spawn_ray(si.hit, sc.wi);
+                                                W.ray_o[p + W.n_paths] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
+                                                W.ray_d[p + W.n_paths] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
+                                                mis_f = f; mis_pdf = sc.pdf; ps |= PS_MIS; push_mis = true;
+                                            }
+                                        }
+                                    }
+                                }
+                                W.pend0[p] = make_float4(ld.r, ld.g, ld.b, mis_w);
+                                W.pend1[p] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf);
+                                W.pend2[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                            }
+                            /* sample the BSDF for the next direction (path.rs:67-76) */
+                            DScatter bs;
+                            const V2 u = rng.next2();
+                            const bool ok = bsdf_sample(B, -ray0.d, u, T_ALL, &bs);
+                            if (ok && !bs.f.is_black()) {
+                                beta = beta * (bs.f * abs_dot(bs.wi, si.shading_n) / bs.pdf);
+                                ps = (bs.type & T_SPECULAR) ? (ps | PS_SPECULAR) : (ps & ~PS_SPECULAR);
+                                DRay nr = spawn_ray(si.hit, bs.wi);
+                                /* Russian roulette (path.rs:84-91) */
+                                if (beta.max_component() < P.rr_threshold && bounces > 3) {
+                                    float q = fmax_(0.05f, 1.0f - beta.max_component());
+                                    if (rng.next() < q) alive = false; else beta = beta / (1.0f - q);
+                                }
+                                if (alive) {
+                                    W.ray_o[p] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray_d[p] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
+                                    bounces += 1; push_closest = true;
+                                }
+                            } else alive = false;
+                        }
+                    }
+                    W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3);
+                }
+                ps = (ps & ~(PS_BOUNCE_MASK | PS_ALIVE)) | (bounces & PS_BOUNCE_MASK) | (alive ? PS_ALIVE : 0u);
+                W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));
+                W.rad[p] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word));
+                push_active = alive || (ps & PS_DIRECT);        /* finished paths with a pending direct term come back once */
+            }
+        }
+        wave_push(push_active, p, out_q, out_count);
+        wave_push(push_closest, p, W.q_closest, &W.counters[2]);
+        wave_push(push_mis, p | WF_MIS_BIT, W.q_closest, &W.counters[2]);
+        wave_push(push_shadow, p, W.q_shadow, &W.counters[3]);
+    }
+    if (err) atomicCAS(&P.stats->error, 0, err);
+}
+
+/* counters housekeeping between kernels (one tiny launch instead of host round trips) */
+__global__ void k_wf_reset(WfBuffers W, int mode, int in_q) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (mode == 0) { for (int i = 0; i < 8; i++) W.counters[i] = 0; }                       /* new pass */
+    else if (mode == 1) { W.counters[2] = 0; W.counters[3] = 0; W.counters[4] = 0; W.counters[5] = 0; W.counters[in_q == 0 ? 1 : 0] = 0; }   /* before shade */
+}
+
+/* ------------------------------------------------------------------ accumulate: add_sample_to_tile in sample order */
+struct FilmCtxW { int crop[4]; int tpb[4]; int sb[4]; float radius[2]; };
+__device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 p_film, Rgb L, int own_x, int own_y, float4* acc, uint32_t* spill) {
+    float pdx = p_film.x - 0.5f, pdy = p_film.y - 0.5f;
+    int p0x = f2i_sat(ceilf(pdx - F.radius[0])), p0y = f2i_sat(ceilf(pdy - F.radius[1]));
+    int p1x = f2i_sat(floorf(pdx + F.radius[0])) + 1, p1y = f2i_sat(floorf(pdy + F.radius[1])) + 1;
+    p0x = max(p0x, F.tpb[0]); p0y = max(p0y, F.tpb[1]); p1x = min(p1x, F.tpb[2]); p1y = min(p1y, F.tpb[3]);
+    const Rgb contrib = L * 1.0f * 1.0f;                     /* radiance * sample_weight * filter_weight (box: 1.0) */
+    int touched = 0;
+    const size_t width = (size_t)(F.crop[2] - F.crop[0]);
+    for (int y = p0y; y < p1y; y++)
+        for (int x = p0x; x < p1x; x++) {
+            touched++;
+            if (x == own_x && y == own_y) { acc->x += contrib.r; acc->y += contrib.g; acc->z += contrib.b; acc->w += 1.0f; continue; }
+            const bool in_tile = x >= F.sb[0] && x < F.sb[2] && y >= F.sb[1] && y < F.sb[3];
+            float* f = reinterpret_cast<float*>((in_tile ? P.accB : P.accC) + ((size_t)(y - F.crop[1]) * width + (size_t)(x - F.crop[0])));
+            atomicAdd(f + 0, contrib.r); atomicAdd(f + 1, contrib.g); atomicAdd(f + 2, contrib.b); atomicAdd(f + 3, 1.0f);
+        }
+    if (touched != 1) (*spill)++;
+}
+__global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers W) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    uint32_t spill = 0, cam = 0; int err = 0;
+    if (slot < W.n_slots) {
+        const DTile tile = P.tiles[slot >> 8];
+        const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
+        if (px < tile.x1 && py < tile.y1) {
+            FilmCtxW F;
+            for (int i = 0; i < 4; i++) F.crop[i] = P.crop[i];
+            F.sb[0] = tile.x0; F.sb[1] = tile.y0; F.sb[2] = tile.x1; F.sb[3] = tile.y1; F.radius[0] = P.radius[0]; F.radius[1] = P.radius[1];
+            int p0x = f2i_sat(ceilf((float)tile.x0 - 0.5f - P.radius[0])), p0y = f2i_sat(ceilf((float)tile.y0 - 0.5f - P.radius[1]));
+            int p1x = f2i_sat(ceilf((float)tile.x1 - 0.5f + P.radius[0] + 1.0f)), p1y = f2i_sat(ceilf((float)tile.y1 - 0.5f - P.radius[1] + 1.0f));
+            F.tpb[0] = max(p0x, P.crop[0]); F.tpb[1] = max(p0y, P.crop[1]); F.tpb[2] = min(p1x, P.crop[2]); F.tpb[3] = min(p1y, P.crop[3]);
+            const bool in_crop = px >= P.crop[0] && px < P.crop[2] && py >= P.crop[1] && py < P.crop[3];
+            const size_t ai = in_crop ? ((size_t)(py - P.crop[1]) * (size_t)(P.crop[2] - P.crop[0]) + (size_t)(px - P.crop[0])) : 0;
+            float4 acc = in_crop ? P.accA[ai] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (uint32_t s = 0; s < W.samples; s++) {
+                const float4 l = W.rad[s * W.n_slots + slot];
+                Rgb L(l.x, l.y, l.z);
+                if (L.has_nans()) err = FTN_ERR_NAN_RADIANCE;
+                Rng rng; rng.seed(indexed_key(P.seed, px, py, W.first_sample + s));
+                V2 j = rng.next2();
+                wf_film_add(P, F, V2((float)px + j.x, (float)py + j.y), L, in_crop ? px : (-2147483647), py, &acc, &spill);
+                cam++;
+            }
+            if (in_crop) P.accA[ai] = acc;
+        }
+    }
+    unsigned long long c = cam, sp = spill;
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); sp += __shfl_down(sp, off, 64); }
+    if (lane_id() == 0) { if (c) atomicAdd(&P.stats->camera_samples, c); if (sp) atomicAdd(&P.stats->spill_samples, sp); }
+    if (err) atomicCAS(&P.stats->error, 0, err);
+}
+
+/* ================================================================== host driver */
+static thread_local std::string g_wf_err;
+const char* wavefront_error() { return g_wf_err.c_str(); }
+
+struct WavefrontState {
+    size_t cap_paths = 0;
+    void* mem[24]; int n_mem = 0;
+    WfBuffers W;
+    hipEvent_t ev[64]; int n_ev = 0;
+    uint32_t* host_counters = nullptr;    /* pinned */
+    int n_cu = 256;
+};
+#define WF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_wf_err = std::string(#expr ": ") + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE; } } while (0)
+
+static void wf_free(WavefrontState* st) { for (int i = 0; i < st->n_mem; i++) (void)hipFree(st->mem[i]); st->n_mem = 0; st->cap_paths = 0; }
+void wavefront_destroy(WavefrontState* st) {
+    if (!st) return;
+    wf_free(st);
+    for (int i = 0; i < st->n_ev; i++) (void)hipEventDestroy(st->ev[i]);
+    if (st->host_counters) (void)hipHostFree(st->host_counters);
+    delete st;
+}
+template <class T> static int wf_alloc(WavefrontState* st, T** p, size_t n) {
+    WF_TRY(hipMalloc((void**)p, n * sizeof(T)));
+    st->mem[st->n_mem++] = (void*)*p;
+    return FTN_OK;
+}
+static int wf_reserve(WavefrontState* st, size_t n) {
+    if (n <= st->cap_paths) return FTN_OK;
+    wf_free(st);
+    WfBuffers& W = st->W; int rc;
+    if ((rc = wf_alloc(st, &W.ray_o, 2 * n)) || (rc = wf_alloc(st, &W.ray_d, 2 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
+        (rc = wf_alloc(st, &W.sh_o, n)) || (rc = wf_alloc(st, &W.sh_d, n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
+        (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
+        (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) ||
+        (rc = wf_alloc(st, &W.counters, 8))) return rc;
+    st->cap_paths = n;
+    return FTN_OK;
+}
+
+int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times) {
+    if (!*state) {
+        *state = new WavefrontState();
+        for (int i = 0; i < 64; i++) { WF_TRY(hipEventCreate(&(*state)->ev[i])); (*state)->n_ev = i + 1; }
+        WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 8 * sizeof(uint32_t)));
+        hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
+        (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    WavefrontState* st = *state;
+    RenderParams P = P0;
+    const uint32_t n_slots = (uint32_t)tiles.size() * 256u;
+    if (n_slots == 0) return FTN_OK;
+    const uint32_t total_samples = P.last_sample - P.first_sample;
+    if (total_samples == 0) return FTN_OK;
+    /* samples per pass: about 8M paths in flight (enough to fill 256 CUs for every bounce, bounded HBM) */
+    uint32_t S = (uint32_t)std::max<size_t>(1, (size_t)(8u << 20) / n_slots);
+    S = std::min(S, total_samples);
+    int rc = wf_reserve(st, (size_t)S * n_slots); if (rc) return rc;
+    WfBuffers W = st->W;
+    const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
+    const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
+    const unsigned shade_grid_max = (unsigned)st->n_cu * 8u;
+    double trace_ms = 0.0; unsigned long long trace_launches = 0;
+    int ev_used = 0;
+    struct Span { int a, b; };
+    std::vector<Span> spans;
+    auto flush_events = [&]() -> int {
+        if (spans.empty()) return FTN_OK;
+        WF_TRY(hipEventSynchronize(st->ev[spans.back().b]));
+        for (const Span& s : spans) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, st->ev[s.a], st->ev[s.b]); trace_ms += ms; }
+        spans.clear(); ev_used = 0;
+        return FTN_OK;
+    };
+    for (uint32_t s0 = 0; s0 < total_samples; s0 += S) {
+        const uint32_t Sp = std::min(S, total_samples - s0);
+        W.n_slots = n_slots; W.samples = Sp; W.n_paths = Sp * n_slots; W.first_sample = P.first_sample + s0;
+        hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 0, 0);
+        hipLaunchKernelGGL(k_wf_generate, dim3((W.n_paths + 255) / 256), dim3(256), 0, stream, P, W);
+        int in_q = 0;
+        const uint32_t max_iter = P.max_depth + 2 + 64;     /* +64: null-material pass-throughs do not count as bounces */
+        for (uint32_t it = 0; it < max_iter; it++) {
+            const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
+            if (ev_used + 2 > 64) { rc = flush_events(); if (rc) return rc; }
+            WF_TRY(hipEventRecord(st->ev[ev_used], stream));
+            if (count) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(tg), dim3(256), lds, stream, P.S, W, W.q_closest, &W.counters[2], &W.counters[4], P.stats, 24u);
+            else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(tg), dim3(256), lds, stream, P.S, W, W.q_closest, &W.counters[2], &W.counters[4], P.stats, 24u);
+            WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
+            spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
+            if (it > 0) {
+                const unsigned sg = std::min<unsigned>(trace_grid_max, (W.n_paths + 255) / 256);
+                if (count) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(sg), dim3(256), lds, stream, P.S, W, W.q_shadow, &W.counters[3], &W.counters[5], P.stats, 24u);
+                else hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(sg), dim3(256), lds, stream, P.S, W, W.q_shadow, &W.counters[3], &W.counters[5], P.stats, 24u);
+            }
+            hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q);
+            hipLaunchKernelGGL(k_wf_shade, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
+            in_q ^= 1;
+            if (it >= P.max_depth) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
+                WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                WF_TRY(hipStreamSynchronize(stream));
+                if (st->host_counters[in_q == 0 ? 0 : 1] == 0) break;
+            }
+        }
+        hipLaunchKernelGGL(k_wf_accumulate, dim3((n_slots + 255) / 256), dim3(256), 0, stream, P, W);
+    }
+    rc = flush_events(); if (rc) return rc;
+    WF_TRY(hipGetLastError());
+    if (times) { times->trace_ms = trace_ms; times->trace_launches = trace_launches; }
+    return FTN_OK;
+}
+
+}  // namespace ftn

@@ -238,9 +238,11 @@ typedef struct ftn_stats {
     uint64_t camera_samples;
     uint64_t spill_samples;     /* film samples that touched more than one pixel (film.rs:138-139)   */
     double kernel_ms;           /* device time of the render kernels (HIP events)                    */
-    double trace_ms;            /* device time of the traversal kernels alone (wavefront)            */
-    uint64_t trace_launches;
-    uint64_t reserved[3];
+    double trace_ms;            /* device time of the closest-hit traversal kernel launches (wavefront)     */
+    uint64_t trace_launches;    /* closest-hit traversal launches timed by trace_ms (wavefront)            */
+    uint64_t nodes_visited_any; /* the share of nodes_visited / prims_tested spent in intersect_test rays   */
+    uint64_t prims_tested_any;
+    uint64_t reserved[1];
 } ftn_stats;
 
 /* ------------------------------------------------------------------ host-side constructors
@@ -334,6 +336,12 @@ int ftn_render_device(const ftn_scene* scene, const ftn_camera_desc* camera, con
                       const ftn_sampler_desc* sampler, const ftn_integrator_desc* integrator,
                       const ftn_tile_range* tiles, const ftn_render_options* options,
                       void* device_pixels, void* stream, ftn_stats* stats);
+
+/* ------------------------------------------------------------------ test hook
+ * Evaluates the deterministic math of the kernels ON THE DEVICE for arrays of HOST floats (parity tests compare the bits
+ * with a CPU evaluation): which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x,y), 6 ln, 7 log2, 8 sqrt, 9 x/y,
+ * 10 (float)sqrt((double)x * y)  [the f64 path of math.rs:37-42], 11 next_float_up, 12 next_float_down.                 */
+int ftn_test_math(int which, const float* x, const float* y, size_t n, float* out);
 
 /* ------------------------------------------------------------------ misc */
 const char* ftn_last_error(void);

@@ -165,7 +165,7 @@ int orc_render(const orc_scene* s, const ftn_camera_desc* cam, const ftn_film_de
                ftn_pixel* out_pixels, ftn_stats* stats) {
     SceneData& scene = const_cast<SceneData&>(s->data);
     scene.count_traffic = count_traffic != 0;
-    scene.rays_closest = 0; scene.rays_any = 0; scene.nodes_visited = 0; scene.prims_tested = 0; scene.error = 0;
+    scene.rays_closest = 0; scene.rays_any = 0; scene.nodes_visited = 0; scene.prims_tested = 0; scene.nodes_any = 0; scene.prims_any = 0; scene.error = 0;
     Camera camera;
     camera.camera_to_world = from_abi(&cam->camera_to_world); camera.raster_to_camera = from_abi(&cam->raster_to_camera);
     camera.shutter_open = cam->shutter_open; camera.shutter_close = cam->shutter_close;
@@ -209,6 +209,7 @@ int orc_render(const orc_scene* s, const ftn_camera_desc* cam, const ftn_film_de
         memset(stats, 0, sizeof(*stats));
         stats->rays_closest = scene.rays_closest; stats->rays_any = scene.rays_any;
         stats->nodes_visited = scene.nodes_visited; stats->prims_tested = scene.prims_tested;
+        stats->nodes_visited_any = scene.nodes_any; stats->prims_tested_any = scene.prims_any;
         stats->camera_samples = cs; stats->spill_samples = spill;
         stats->kernel_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     }

@@ -4,6 +4,7 @@
 #pragma once
 #include "orc_reflection.hpp"
 #include <memory>
+#include <deque>
 #include <atomic>
 
 namespace orc {
@@ -209,13 +210,13 @@ struct BVH {
             std::swap(data[l], data[r]);
         }
     }
-    static BuildNode* recursive_build(std::vector<std::unique_ptr<BuildNode>>& arena, PrimInfo* info, size_t n,
+    static BuildNode* recursive_build(std::deque<BuildNode>& arena, PrimInfo* info, size_t n,
                                       std::vector<int64_t>& ordering, uint32_t depth, uint32_t* max_depth) {   // :66-120
         if (depth > *max_depth) *max_depth = depth;
         Bounds3 node_bounds = Bounds3::empty(), centroid_bounds = Bounds3::empty();
         for (size_t i = 0; i < n; i++) { node_bounds = node_bounds.join(info[i].bounds); centroid_bounds = centroid_bounds.join_point(info[i].centroid); }
-        arena.emplace_back(new BuildNode());
-        BuildNode* node = arena.back().get();
+        arena.emplace_back();
+        BuildNode* node = &arena.back();
         if (n == 1 || centroid_bounds.is_point()) {
             node->leaf = true; node->first_prim_idx = (uint32_t)ordering.size(); node->n_prims = (uint16_t)n; node->bounds = node_bounds;
             for (size_t i = 0; i < n; i++) ordering.push_back((int64_t)info[i].prim_id);
@@ -256,7 +257,7 @@ struct BVH {
         if (prims.empty()) { bounds = Bounds3::empty(); return; }
         std::vector<PrimInfo> info(prims.size());
         for (size_t i = 0; i < prims.size(); i++) { info[i].prim_id = i; info[i].bounds = prims[i].shape->world_bound(); info[i].centroid = info[i].bounds.centroid(); }
-        std::vector<std::unique_ptr<BuildNode>> arena;
+        std::deque<BuildNode> arena;   // bumpalo arena in the reference
         std::vector<int64_t> ordering; ordering.reserve(prims.size());
         BuildNode* root = recursive_build(arena, info.data(), info.size(), ordering, 0, &max_depth);
         bounds = root->bounds;
@@ -339,7 +340,7 @@ struct SceneData {
     std::vector<Light> lights;
     BVH bvh;
     // statistics (atomics: the renderer is tile-parallel)
-    mutable std::atomic<uint64_t> rays_closest{0}, rays_any{0}, nodes_visited{0}, prims_tested{0};
+    mutable std::atomic<uint64_t> rays_closest{0}, rays_any{0}, nodes_visited{0}, prims_tested{0}, nodes_any{0}, prims_any{0};
     mutable std::atomic<int> error{0};   // 0 ok; FTN_ERR_* otherwise
     bool count_traffic = false;
 
@@ -355,7 +356,8 @@ struct SceneData {
         TraversalCounters c; bool deep = false;
         bool hit = bvh.intersect_test(ray, count_traffic ? &c : nullptr, &deep);
         rays_any.fetch_add(1, std::memory_order_relaxed);
-        if (count_traffic) { nodes_visited.fetch_add(c.nodes_visited, std::memory_order_relaxed); prims_tested.fetch_add(c.prims_tested, std::memory_order_relaxed); }
+        if (count_traffic) { nodes_visited.fetch_add(c.nodes_visited, std::memory_order_relaxed); prims_tested.fetch_add(c.prims_tested, std::memory_order_relaxed);
+                             nodes_any.fetch_add(c.nodes_visited, std::memory_order_relaxed); prims_any.fetch_add(c.prims_tested, std::memory_order_relaxed); }
         if (deep) error.store(FTN_ERR_BVH_TOO_DEEP);
         return hit;
     }

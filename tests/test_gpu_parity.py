@@ -1,0 +1,247 @@
+"""GPU parity tests proper (-m gpu): the HIP path through the C ABI against the CPU oracle on identical inputs.
+Bar: bit-exact (f32 radiance is computed with the same operation order and the same deterministic math); the only
+tolerated deviation is the last bit of film pixels that received a "spill" sample (a sample whose f32 film position
+lands on a pixel boundary and is added to two pixels, film.rs:138-139) -- see DESIGN.md, film accumulation.
+Against the libm build of the oracle (what rustc would link) the agreement is statistical; the measured RMSE is
+asserted against the tolerance stated in each test."""
+import numpy as np
+import pytest
+
+from fountain_amd import (DirectLightingIntegrator, Film, FountainError, PathIntegrator, PerspectiveCamera, RandomSampler,
+                          SamplerIntegrator, SceneBuilder, _abi as A, make_rays, scenes)
+
+pytestmark = pytest.mark.gpu
+MEGA, WAVE = A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT
+
+
+def unit_dirs(n, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_film_equal(px_gpu, px_ref, n_spill, what):
+    """Bit-exact except (at most) the pixels touched by spill samples, which may differ by a few ulp."""
+    diff = (bits(px_gpu) != bits(px_ref)).any(axis=-1)
+    assert int(diff.sum()) <= 4 * n_spill, "%s: %d pixels differ, only %d spill samples" % (what, int(diff.sum()), n_spill)
+    assert np.allclose(px_gpu, px_ref, rtol=2e-6, atol=1e-7), what
+
+
+def render_pair(gpu, ref, make, integ, sampler, pipeline, **kw):
+    out = []
+    for be in (gpu, ref):
+        b, cam, res = make(be)
+        bk = dict(pipeline=pipeline, count_traffic=True) if be is gpu else dict(count_traffic=True)
+        rgb, px, st, _ = scenes.render(be, b, cam, res, integ, sampler, backend_kwargs=bk, **kw)
+        out.append((rgb, px, st))
+    return out
+
+
+# ------------------------------------------------------------------ traversal (Scene::intersect / intersect_test)
+def cube_scene(be):
+    P, N, F = scenes.rounded_cube_mesh()
+    b = SceneBuilder(be)
+    b.material("none")
+    b.shape("trianglemesh", P=P, N=N, indices=F)
+    return b.create_scene()
+
+
+def test_rounded_cube_watertight_and_bit_exact(gpu, orc_det):
+    """tests/tri_watertight.rs on the GPU, plus hit records / shading geometry / node+triangle counts equal to the oracle's"""
+    sg, so = cube_scene(gpu), cube_scene(orc_det)
+    rays = make_rays(np.zeros((1, 3), np.float32), unit_dirs(100000, 11))
+    occ, sa = sg.intersect_test(rays)
+    t, prim, bary, sc = sg.intersect(rays)
+    assert occ.all() and (prim >= 0).all()
+    to, po, _, sco = so.intersect(rays)
+    oo, sao = so.intersect_test(rays)
+    assert np.array_equal(bits(t), bits(to)) and np.array_equal(prim, po) and np.array_equal(occ, oo)
+    assert sc["nodes_visited"] == sco["nodes_visited"] and sc["prims_tested"] == sco["prims_tested"]
+    assert sa["nodes_visited"] == sao["nodes_visited"] and sa["prims_tested"] == sao["prims_tested"]
+    assert np.allclose(bary.sum(1), 1.0, atol=1e-5)
+    fg, fo = sg.intersect_full(rays[:20000]), so.intersect_full(rays[:20000])
+    for sl in (slice(0, 9), slice(11, 14), slice(20, 24)):          # p, p_err, n | wo | shading_n, t
+        assert np.array_equal(bits(fg[:, sl]), bits(fo[:, sl]))
+
+
+def test_rays_from_outside_and_short_rays(gpu, orc_det):
+    """misses, grazing rays, finite t_max (shadow-ray style) and rays starting on the surface"""
+    sg, so = cube_scene(gpu), cube_scene(orc_det)
+    rng = np.random.default_rng(2)
+    o = rng.uniform(-30, 30, (50000, 3)).astype(np.float32)
+    d = unit_dirs(50000, 3) * rng.uniform(0.1, 40, (50000, 1)).astype(np.float32)
+    rays = make_rays(o, d, t_max=rng.choice([np.inf, 1.0 - 1e-4, 0.5], 50000).astype(np.float32))
+    t, prim, _, _ = sg.intersect(rays)
+    to, po, _, _ = so.intersect(rays)
+    assert np.array_equal(bits(t), bits(to)) and np.array_equal(prim, po)
+    assert 0 < (prim >= 0).sum() < len(prim)
+    assert np.array_equal(sg.intersect_test(rays)[0], so.intersect_test(rays)[0])
+
+
+def test_sphere_bvh_vs_oracle(gpu, orc_det):
+    """src/bvh.rs:401-444 scene (100 random spheres) on the GPU: any-hit <=> closest-hit, hits equal to the oracle's"""
+    def make(be):
+        rng = np.random.default_rng(3)
+        b = SceneBuilder(be)
+        b.material("none")
+        for c, r in zip(rng.uniform(-10, 10, (100, 3)), rng.uniform(0.5, 3.0, 100)):
+            b.attribute_begin(); b.translate(c); b.shape("sphere", radius=float(r)); b.attribute_end()
+        return b.create_scene()
+    sg, so = make(gpu), make(orc_det)
+    rays = make_rays(np.zeros((1, 3), np.float32), unit_dirs(5000, 9))
+    t, prim, _, _ = sg.intersect(rays)
+    occ, _ = sg.intersect_test(rays)
+    to, po, _, _ = so.intersect(rays)
+    assert np.array_equal(occ, prim >= 0)
+    assert np.array_equal(bits(t), bits(to)) and np.array_equal(prim, po)
+    assert np.array_equal(bits(sg.intersect_full(rays)[:, :9]), bits(so.intersect_full(rays)[:, :9]))
+
+
+def test_empty_scene(gpu):
+    sc = SceneBuilder(gpu).create_scene()
+    t, prim, _, _ = sc.intersect(make_rays([(0, 0, 0)], unit_dirs(100, 1)))
+    assert (prim == -1).all() and np.isinf(t).all()
+
+
+# ------------------------------------------------------------------ tests/furnace.rs on the GPU
+@pytest.mark.parametrize("name,integ,expected,eps", [
+    ("path", PathIntegrator.new(10, 1.0), 2.0, 0.1),
+    ("path_no_rr", PathIntegrator.new(10, 0.0), 2.0, 0.001),
+    ("directlighting", DirectLightingIntegrator(3), 1.5, 1e-5)])
+def test_furnace_reference_sampler(gpu, orc_det, name, integ, expected, eps):
+    """The three assertions of tests/furnace.rs with the reference's per-tile RandomSampler stream (one serial lane per tile)."""
+    (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, scenes.furnace, integ, RandomSampler(128, 0), MEGA)
+    assert np.abs(rgb - expected).max() <= eps
+    assert np.array_equal(bits(px), bits(pxo))
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+
+
+@pytest.mark.parametrize("pipeline", [MEGA, WAVE])
+def test_furnace_indexed_sampler(gpu, orc_det, pipeline):
+    (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, scenes.furnace, PathIntegrator.new(10, 1.0), RandomSampler(128, 0, indexed=True), pipeline)
+    assert np.abs(rgb - 2.0).max() <= 0.1
+    assert_film_equal(px, pxo, st["spill_samples"], "furnace")
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+
+
+# ------------------------------------------------------------------ render parity
+def _materials_scene(be):
+    """every material / lobe the reference implements: OrenNayar matte, anisotropic metal, plastic, rough glass, mirror;
+    point + distant + area lights; thin-lens camera"""
+    b = SceneBuilder(be)
+    b.light_source("point", I=(40, 40, 40), from_=(0, -2, 3))
+    b.light_source("distant", L=(1.5, 1.4, 1.2), from_=(1, -1, 2), to=(0, 0, 0))
+    b.material("matte", Kd=(0.6, 0.6, 0.6), sigma=25.0)
+    scenes._quad(b, (-6, -6, -1), (6, -6, -1), (6, 6, -1), (-6, 6, -1))
+    b.attribute_begin(); b.material("matte", Kd=(0, 0, 0)); b.area_light_source("diffuse", L=(8, 8, 8)); b.translate((0, 0, 4)); b.reverse_orientation(); b.shape("sphere", radius=0.5, zmin=-0.5, zmax=0.2); b.attribute_end()
+    specs = [("metal", dict(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), uroughness=0.02, vroughness=0.2)), ("plastic", dict(Kd=(0.3, 0.1, 0.1), Ks=(0.4, 0.4, 0.4), roughness=0.05)),
+             ("glass", dict(uroughness=0.1, vroughness=0.1, eta=1.5)), ("mirror", dict()), ("metal", dict(eta=(1.5, 1.0, 0.5), k=(3, 2.5, 2), roughness=0.3, remaproughness=False))]
+    for i, (m, kw) in enumerate(specs):
+        b.attribute_begin(); b.material(m, **kw); b.translate((-2.4 + 1.2 * i, 0.2 * i, -0.45)); b.rotate(30.0 * i, (0.2, 0.3, 1)); b.scale(1, 1, 0.9); b.shape("sphere", radius=0.55); b.attribute_end()
+    cam = PerspectiveCamera.look_at(be, (0, -7, 2.5), (0, 0, -0.3), (0, 0, 1), (96, 64), fov=42.0, lens_radius=0.08, focal_dist=7.3)
+    return b, cam, (96, 64)
+
+
+SCENES = {
+    "cornell": (lambda be: scenes.cornell(be, res=96), 8),
+    "cube_env": (lambda be: scenes.rounded_cube_env(be, res=96, env_n=64), 8),
+    "materials": (_materials_scene, 8),
+    "cubes27": (lambda be: scenes.instanced_cubes(be, n_copies=27, res=(80, 80), env_n=32, lens_radius=0.3), 4),
+}
+
+
+@pytest.mark.parametrize("pipeline", [MEGA, WAVE])
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_render_matches_oracle(gpu, orc_det, scene, pipeline):
+    make, spp = SCENES[scene]
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, make, PathIntegrator.new(5, 1.0), RandomSampler(spp, 0, indexed=True), pipeline)
+    assert rgb.mean() > 0.01 and np.isfinite(rgb).all()
+    assert_film_equal(px, pxo, st["spill_samples"], scene)
+    for k in ("rays_closest", "rays_any", "nodes_visited", "prims_tested", "camera_samples", "spill_samples"):
+        assert st[k] == sto[k], (k, st[k], sto[k])
+    rmse = float(np.sqrt(((rgb.astype(np.float64) - rgbo) ** 2).mean()))
+    assert rmse <= 1e-4        # BASELINE.json: per-pixel RMSE <= 1e-4 vs the CPU reference
+
+
+@pytest.mark.parametrize("scene", ["cornell", "cube_env"])
+def test_render_vs_libm_oracle(gpu, orc, scene):
+    """Against the oracle built like the reference (transcendentals from libm): <= 1 ulp differences in sin/cos/acos/atan2
+    can flip a branch, which moves a pixel by O(L/spp); otherwise pixels differ in the last bits.  Stated tolerance:
+    BASELINE.json's per-pixel RMSE <= 1e-4 (measured on MI355X: 7e-9), with more than half of the pixels bit-identical."""
+    make, spp = SCENES[scene]
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc, make, PathIntegrator.new(5, 1.0), RandomSampler(spp, 0, indexed=True), WAVE)
+    same = (bits(px) == bits(pxo)).all(axis=-1).mean()
+    rmse = float(np.sqrt(((rgb.astype(np.float64) - rgbo) ** 2).mean()))
+    assert same >= 0.5 and rmse <= 1e-4, (same, rmse)
+
+
+def test_tile_serial_reference_stream(gpu, orc_det):
+    """The reference's exact RandomSampler (one Xoshiro256+ stream per 16x16 tile) on a triangle + sphere scene"""
+    (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, lambda be: scenes.cornell(be, res=32), PathIntegrator.new(5, 1.0), RandomSampler(2, 0), MEGA)
+    assert_film_equal(px, pxo, st["spill_samples"], "cornell tile-serial")
+    assert st["rays_closest"] == sto["rays_closest"]
+
+
+def test_direct_lighting_with_mirror_chain(gpu, orc_det):
+    (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, lambda be: scenes.cornell(be, res=48), DirectLightingIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA)
+    assert_film_equal(px, pxo, st["spill_samples"], "cornell direct lighting")
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE sizes
+def test_config2_sample_ranges_and_tile_shards_compose(gpu):
+    """Cornell 512x512 (config 2): rendering samples [0,8)+[8,16) in two calls equals one call of 16 (in-order film sums), and
+    interleaved tile shards (the multi-GPU decomposition) added into one film equal the unsharded render -- bit for bit."""
+    b, cam, res = scenes.cornell(gpu, res=512)
+    sc = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    whole = Film(gpu, res)
+    st = si.render_parallel(sc, whole, RandomSampler(16, 0, indexed=True), pipeline=WAVE)
+    assert st["camera_samples"] == 512 * 512 * 16
+    shards = Film(gpu, res)
+    for r in range(4):
+        si.render_parallel(sc, shards, RandomSampler(16, 0, indexed=True), tiles=(r, 4, 0), pipeline=WAVE)
+    assert_film_equal(shards.pixels, whole.pixels, st["spill_samples"], "tile shards")
+    mega = Film(gpu, res)
+    si.render_parallel(sc, mega, RandomSampler(16, 0, indexed=True), pipeline=MEGA)
+    assert_film_equal(mega.pixels, whole.pixels, st["spill_samples"], "megakernel vs wavefront")
+    rgb, _ = whole.into_spectrum_buffer()
+    assert np.isfinite(rgb).all() and 0.05 < rgb.mean() < 5.0
+    # weights: every pixel received exactly 16 samples (+ spills)
+    assert np.all(whole.pixels[..., 3] >= 16) and whole.pixels[..., 3].sum() == 512 * 512 * 16 + (whole.pixels[..., 3] - 16).sum()
+
+
+def test_furnace_256_energy(gpu):
+    """config 1 geometry at 256x256x16: the furnace value 2 - 2^-(depth) holds for every pixel without Russian roulette"""
+    b, cam, res = scenes.furnace(gpu, res=256)
+    rgb, px, st, _ = scenes.render(gpu, b, cam, res, PathIntegrator.new(5, 0.0), RandomSampler(16, 0, indexed=True), backend_kwargs=dict(pipeline=WAVE))
+    assert np.abs(rgb - (2.0 - 2.0 ** -5)).max() < 2e-2
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_specular_glass_reports_unsupported(gpu):
+    b = SceneBuilder(gpu)
+    b.light_source("point", I=(10, 10, 10), from_=(0, 0, 5))
+    b.material("glass", remaproughness=False)
+    b.shape("sphere", radius=1.0)
+    cam = PerspectiveCamera.look_at(gpu, (0, -4, 0), (0, 0, 0), (0, 0, 1), (16, 16), fov=40.0)
+    for pl in (MEGA, WAVE):
+        with pytest.raises(FountainError) as e:
+            scenes.render(gpu, b, cam, (16, 16), PathIntegrator.new(5, 1.0), RandomSampler(2, 0, indexed=True), backend_kwargs=dict(pipeline=pl))
+        assert e.value.code == A.FTN_ERR_UNSUPPORTED
+
+
+def test_null_material_pass_through(gpu, orc_det):
+    """path.rs:77-81: a primitive without material is skipped without counting a bounce"""
+    def make(be):
+        b, cam, res = scenes.cornell(be, res=48)
+        b.attribute_begin(); b.material("none"); b.translate((0, -1.5, 0)); b.shape("sphere", radius=0.5); b.attribute_end()
+        return b, cam, res
+    for pl in (MEGA, WAVE):
+        (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, make, PathIntegrator.new(3, 1.0), RandomSampler(4, 0, indexed=True), pl)
+        assert_film_equal(px, pxo, st["spill_samples"], "null material")
+        assert st["rays_closest"] == sto["rays_closest"]
