@@ -53,7 +53,7 @@ struct DScene {
     const float4* nodes; const float4* geom; const uint4* prim_info;
     const float* N; const float* UV;
     const DSphere* spheres; const ftn_material* materials; const DLight* lights;
-    uint32_t n_nodes, n_prims, n_lights, n_inf_lights;
+    uint32_t n_nodes, n_prims, n_lights, n_inf_lights, n_spheres, _pad;
     const uint32_t* inf_lights;             /* indices of infinite lights (environment_emitted_radiance sums all lights) */
 };
 

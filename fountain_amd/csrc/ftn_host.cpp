@@ -175,7 +175,7 @@ int ftn_film_sample_bounds(const ftn_film_desc* f, int32_t o[4]) {              
 static void list_tiles(const ftn_film_desc* f, std::vector<DTile>* tiles) {        /* bounds.rs:85-97, integrator/mod.rs:182-185 */
     int32_t sb[4]; ftn_film_sample_bounds(f, sb);
     for (int y = sb[1]; y < sb[3]; y += 16) for (int x = sb[0]; x < sb[2]; x += 16) {
-        DTile t; t.x0 = x; t.y0 = y; t.x1 = std::min(x + 16, sb[2]); t.y1 = std::min(y + 16, sb[3]);
+        DTile t; t.valid_off = 0; t._pad = 0; t.x0 = x; t.y0 = y; t.x1 = std::min(x + 16, sb[2]); t.y1 = std::min(y + 16, sb[3]);
         t.tile_id = (unsigned long long)(long long)(t.y0 * sb[2] + t.x0);
         tiles->push_back(t);
     }
@@ -476,7 +476,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     DScene& D = sc->d; memset(&D, 0, sizeof(D));
     D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
-    D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size();
+    D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
     sc->stack_entries = std::max<uint32_t>(hs.max_depth, 1u);
     if ((rc = sc->stats.alloc_zero(1))) return rc;
     return FTN_OK;
@@ -600,6 +600,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     std::vector<DTile> all, sel; list_tiles(film, &all);
     const uint32_t stride = tr && tr->stride ? tr->stride : 1, first = tr ? tr->first : 0, cnt = tr ? tr->count : 0;
     for (size_t i = first, k = 0; i < all.size() && (cnt == 0 || k < cnt); i += stride, k++) sel.push_back(all[i]);
+    { uint32_t off = 0; for (DTile& t : sel) { t.valid_off = off; t._pad = 0; off += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0)); } }
 
     RenderParams P; memset(&P, 0, sizeof(P));
     P.S = s->d;

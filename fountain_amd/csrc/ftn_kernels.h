@@ -15,7 +15,7 @@ struct DevStats {
     int _pad;
 };
 
-struct DTile { int x0, y0, x1, y1; unsigned long long tile_id; };   /* sample-space tile + its sampler seed */
+struct DTile { int x0, y0, x1, y1; unsigned long long tile_id; uint32_t valid_off, _pad; };   /* sample-space tile, its sampler seed, exclusive prefix sum of pixel counts */
 
 struct RenderParams {
     DScene S; DCamera C;

@@ -21,6 +21,7 @@
  */
 #include "ftn_wavefront.h"
 #include <string>
+#include <cstdlib>
 
 namespace ftn {
 
@@ -44,9 +45,11 @@ struct WfBuffers {
     ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
     uint32_t *q_active[2], *q_closest, *q_shadow;
-    uint32_t* counters;         /* [0] active_in [1] active_out [2] closest [3] shadow [4] head_closest [5] head_shadow */
+    uint32_t* counters;         /* one 128-byte line each (CTR(i) = 32*i): 0 active A, 1 active B, 2 closest, 3 shadow, 4 head closest, 5 head shadow */
+    uint32_t valid_per_sample;  /* camera samples per spp pass (sum of the tiles' pixel counts) */
 };
 
+#define CTR(i) ((i) * 32)
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
 /* wave-level queue append: one atomic per wave (ballot / popc compaction) */
 __device__ inline void wave_push(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
@@ -59,15 +62,42 @@ __device__ inline void wave_push(bool pred, uint32_t value, uint32_t* queue, uin
     if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = value;
 }
 
-/* ------------------------------------------------------------------ generate */
+/* block-level queue append: ballot per wave, ONE global atomic per workgroup and queue (same-address atomics retire at
+ * ~88 per microsecond on this part, so per-wave appends to one word were the bottleneck of generate/shade) */
+template <int NQ>
+__device__ inline void block_push(const bool (&pred)[NQ], const uint32_t (&value)[NQ], uint32_t* const (&queue)[NQ], uint32_t* const (&counter)[NQ]) {
+    __shared__ uint32_t s_cnt[NQ][4];
+    __shared__ uint32_t s_base[NQ];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    unsigned long long m[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { m[q] = __ballot(pred[q]); if (lane == 0) s_cnt[q][wave] = (uint32_t)__popcll(m[q]); }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const uint32_t q = threadIdx.x;
+        const uint32_t tot = s_cnt[q][0] + s_cnt[q][1] + s_cnt[q][2] + s_cnt[q][3];
+        s_base[q] = tot ? atomicAdd(counter[q], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        if (pred[q]) {
+            uint32_t off = s_base[q];
+            for (uint32_t w = 0; w < wave; w++) off += s_cnt[q][w];
+            queue[q][off + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull))] = value[q];
+        }
+    }
+    __syncthreads();   /* s_cnt / s_base are reused by the next round */
+}
+
+/* ------------------------------------------------------------------ generate (no atomics: queue slots are known in closed form) */
 __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;          /* path id = s * n_slots + slot */
     if (i >= W.n_paths) return;
     const uint32_t slot = i % W.n_slots, s = i / W.n_slots;
     const DTile tile = P.tiles[slot >> 8];
     const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
-    const bool valid = px < tile.x1 && py < tile.y1;
-    if (valid) {
+    if (px < tile.x1 && py < tile.y1) {
         Rng rng; rng.seed(indexed_key(P.seed, px, py, W.first_sample + s));
         V2 j = rng.next2();
         V2 p_film((float)px + j.x, (float)py + j.y);
@@ -79,97 +109,158 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
         W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
+        const uint32_t qi = s * W.valid_per_sample + tile.valid_off + (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
+        W.q_active[0][qi] = i;
+        W.q_closest[qi] = i;
     }
-    /* slots are dense per tile; invalid (clipped) lanes simply never enter a queue */
-    wave_push(valid, i, W.q_active[0], &W.counters[0]);
-    wave_push(valid, i, W.q_closest, &W.counters[2]);
 }
 
-/* ------------------------------------------------------------------ trace */
-template <bool ANY, bool COUNT>
+/* ------------------------------------------------------------------ trace
+ * Per lane: mode 0 = needs a ray, 1 = at a BVH node, 2 = holds a leaf whose primitives are still to be tested.
+ * A wave alternates between two cheap, convergent bodies instead of running the (long) triangle test for the two or three
+ * lanes that happen to sit on a leaf at every step:
+ *     node step   for all lanes in mode 1                         (~40 VALU instructions)
+ *     leaf step   for all lanes in mode 2, once >= leaf_batch lanes wait there or no lane is left in mode 1
+ * The visiting order of every single ray is exactly the reference's (bvh.rs:160-266): near child first, the far child is
+ * re-tested against the shrunken t_max when popped, leaf primitives in order, `t == t_max` accepted.
+ * Rays are taken from the queue in per-wave chunks (one global atomic per `chunk` rays) and lanes are re-armed from the chunk
+ * with __ballot / __popcll prefix ranks as soon as `refill` of them are idle. */
+enum : uint32_t { TM_IDLE = 0, TM_NODE = 1, TM_LEAF = 2 };
+
+template <bool ANY, bool COUNT, bool SPHERES>
 __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
-                                                  DevStats* stats, uint32_t refill_below) {
+                                                  DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk) {
     extern __shared__ uint32_t lds_stack[];
     const LdsStack st{lds_stack + threadIdx.x, 256u};
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
     const uint32_t np = W.n_paths;
     TravCount tc{0, 0};
-    bool active = false, exhausted = false;
-    uint32_t rid = 0, cur = 0, neg = 0; int sp = 0;
-    V3 o, d, inv; float t_max = 0.0f; DHit h; bool found = false;
+    uint32_t mode = TM_IDLE;
+    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
+    uint32_t rid = 0, cur = 0, neg = 0, lp = 0, lp_end = 0; int sp = 0;
+    V3 o, inv, dperm; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kx = 0, ky = 0, kz = 0;
+    int hprim = -1; float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f; bool found = false;
+    V3 dorig;   /* only the sphere path needs the unpermuted direction */
     for (;;) {
-        const unsigned long long need = __ballot(!active);
-        if (need != 0 && !exhausted) {
-            const int leader = __ffsll((long long)need) - 1;
-            const uint32_t n = (uint32_t)__popcll(need);
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(head, n);
-            base = __shfl(base, leader, 64);
-            if (base + n >= count) exhausted = true;
-            const uint32_t my = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            if (!active && my < count) {
-                rid = queue[my];
+        /* ---- re-arm idle lanes */
+        const unsigned long long idle = __ballot(mode == TM_IDLE);
+        if (!exhausted && (uint32_t)__popcll(idle) >= refill) {
+            const uint32_t need = (uint32_t)__popcll(idle);
+            if (chunk_next == chunk_end) {                       /* the wave's chunk is used up: take a new one */
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, chunk);
+                base = __shfl(base, 0, 64);
+                chunk_next = base; chunk_end = base + chunk;
+                if (chunk_next >= count) { exhausted = true; chunk_end = chunk_next; }
+                else if (chunk_end > count) chunk_end = count;
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (mode == TM_IDLE && rank < avail) {
+                rid = queue[chunk_next + rank];
                 const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
                 const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
-                o = V3(a.x, a.y, a.z); d = V3(b.x, b.y, b.z); t_max = b.w;
+                o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
+                if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-                sp = 0; cur = 0; found = false; active = S.n_nodes != 0;
-                h.t = FTN_INF; h.prim = -1; h.b0 = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
-                if (!active) {   /* empty scene: immediate miss */
+                /* Triangle::intersect's per-ray constants (triangle.rs:189-205): permutation and shear depend on the ray only */
+                kz = max_dimension(vabs(d)); kx = kz + 1; if (kx == 3) kx = 0; ky = kx + 1; if (ky == 3) ky = 0;
+                dperm = V3(d.get(kx), d.get(ky), d.get(kz));
+                sx = -dperm.x / dperm.z; sy = -dperm.y / dperm.z; sz = 1.0f / dperm.z;
+                sp = 0; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
+                mode = TM_NODE;
+                if (S.n_nodes == 0) {   /* empty scene: immediate miss */
                     if (ANY) W.occluded[rid] = 0; else { W.hit[r] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[r] = -1; }
+                    mode = TM_IDLE;
                 }
             }
+            chunk_next += (need < avail ? need : avail);
         }
-        if (__ballot(active) == 0) { if (exhausted) break; else continue; }
-        /* walk until too few lanes are left (then refill), or to completion once the queue is drained */
-        for (;;) {
-            if (active) {
+        const unsigned long long m_node = __ballot(mode == TM_NODE), m_leaf = __ballot(mode == TM_LEAF);
+        if ((m_node | m_leaf) == 0) { if (exhausted) break; else continue; }
+        bool finish = false;
+        if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
+            /* ---- node step */
+            if (mode == TM_NODE) {
                 const float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
                 if (COUNT) tc.nodes++;
-                bool pop = true, done = false;
+                bool pop = true;
                 if (slab_test(nlo, nhi, o, inv, t_max)) {
                     const uint32_t idx = __float_as_uint(nlo.w), meta = __float_as_uint(nhi.w);
-                    if (meta >> 24) {
-                        const uint32_t n = meta & 0xffffu;
-                        for (uint32_t k = 0; k < n; k++) {
-                            const uint32_t prim = idx + k;
-                            const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
-                            if (COUNT) tc.prims++;
-                            const uint32_t fl = __float_as_uint(g0.w);
-                            float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh;
-                            if (fl & GF_KIND_SPHERE) { DRay r; r.o = o; r.d = d; r.t_max = t_max; r.time = 0.0f; hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr); }
-                            else {
-                                V3 p0(g0.x, g0.y, g0.z), p1(g1.x, g1.y, g1.z), p2(g2.x, g2.y, g2.z);
-                                hh = tri_hit(o, d, t_max, p0, p1, p2, &t, &b0, &b1, &b2);
-                                if (hh && (fl & GF_HAS_UVS) && tri_uv_degenerate_reject(S, (int)prim, p0, p1, p2)) hh = false;
-                            }
-                            if (hh) {
-                                found = true;
-                                if (ANY) { done = true; break; }
-                                t_max = t; h.t = t; h.prim = (int)prim; h.b0 = b0; h.b1 = b1; h.b2 = b2;
-                            }
-                        }
-                    } else {
+                    if (meta >> 24) { lp = idx; lp_end = idx + (meta & 0xffffu); mode = TM_LEAF; pop = false; }
+                    else {
                         const uint32_t axis = (meta >> 16) & 3u;
                         if ((neg >> axis) & 1u) { st.push(sp++, cur + 1); cur = idx; }
                         else { st.push(sp++, idx); cur = cur + 1; }
                         pop = false;
                     }
                 }
-                if (pop && !done) { if (sp == 0) done = true; else cur = st.pop(--sp); }
-                if (done) {
-                    if (ANY) W.occluded[rid] = found ? 1 : 0;
-                    else {
-                        const uint32_t r = (rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid;
-                        W.hit[r] = make_float4(h.t, h.b0, h.b1, h.b2); W.hit_prim[r] = h.prim;
-                    }
-                    active = false;
-                }
+                if (pop) { if (sp == 0) finish = true; else cur = st.pop(--sp); }
             }
-            const uint32_t alive = (uint32_t)__popcll(__ballot(active));
-            if (alive == 0 || (!exhausted && alive < refill_below)) break;
+        } else {
+            /* ---- leaf step: one primitive per lane */
+            if (mode == TM_LEAF) {
+                const uint32_t prim = lp;
+                const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                if (COUNT) tc.prims++;
+                const uint32_t fl = __float_as_uint(g0.w);
+                float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh = false;
+                if (SPHERES && (fl & GF_KIND_SPHERE)) {
+                    DRay r; r.o = o; r.d = dorig; r.t_max = t_max; r.time = 0.0f;
+                    hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
+                } else {
+                    /* Triangle::intersect hit test (triangle.rs:183-268) with the per-ray constants hoisted */
+                    const V3 op(o.get(kx), o.get(ky), o.get(kz));
+                    V3 p0t(g0.x, g0.y, g0.z), p1t(g1.x, g1.y, g1.z), p2t(g2.x, g2.y, g2.z);
+                    p0t = V3(p0t.get(kx) - op.x, p0t.get(ky) - op.y, p0t.get(kz) - op.z);
+                    p1t = V3(p1t.get(kx) - op.x, p1t.get(ky) - op.y, p1t.get(kz) - op.z);
+                    p2t = V3(p2t.get(kx) - op.x, p2t.get(ky) - op.y, p2t.get(kz) - op.z);
+                    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+                    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+                    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+                    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+                    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+                    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+                    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+                        e0 = (float)((double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x);
+                        e1 = (float)((double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x);
+                        e2 = (float)((double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x);
+                    }
+                    const float det = e0 + e1 + e2;
+                    if (!(sign_pos(e0) != sign_pos(e1) || sign_pos(e1) != sign_pos(e2)) && det != 0.0f) {
+                        p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+                        const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+                        if (!((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)))) {
+                            const float inv_det = 1.0f / det;
+                            b0 = e0 * inv_det; b1 = e1 * inv_det; b2 = e2 * inv_det; t = t_scaled * inv_det;
+                            const float max_zt = fmax_(fmax_(fabsf(p0t.z), fabsf(p1t.z)), fabsf(p2t.z));
+                            const float delta_z = gamma_n(3) * max_zt;
+                            const float max_xt = fmax_(fmax_(fabsf(p0t.x), fabsf(p1t.x)), fabsf(p2t.x));
+                            const float max_yt = fmax_(fmax_(fabsf(p0t.y), fabsf(p1t.y)), fabsf(p2t.y));
+                            const float delta_x = gamma_n(5) * (max_xt + max_zt), delta_y = gamma_n(5) * (max_yt + max_zt);
+                            const float delta_e = 2.0f * (gamma_n(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+                            const float max_e = fmax_(fmax_(fabsf(e0), fabsf(e1)), fabsf(e2));
+                            const float delta_t = 3.0f * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+                            hh = !(t <= delta_t);
+                            if (hh && (fl & GF_HAS_UVS) && tri_uv_degenerate_reject(S, (int)prim, V3(g0.x, g0.y, g0.z), V3(g1.x, g1.y, g1.z), V3(g2.x, g2.y, g2.z))) hh = false;
+                        }
+                    }
+                }
+                if (hh) { found = true; t_max = t; hprim = (int)prim; hb0 = b0; hb1 = b1; hb2 = b2; }
+                lp++;
+                if (ANY && hh) finish = true;
+                else if (lp == lp_end) { if (sp == 0) finish = true; else { cur = st.pop(--sp); mode = TM_NODE; } }
+            }
+        }
+        if (finish) {
+            if (ANY) W.occluded[rid] = found ? 1 : 0;
+            else {
+                const uint32_t r = (rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid;
+                W.hit[r] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[r] = hprim;
+            }
+            mode = TM_IDLE;
         }
     }
     if (COUNT) {
@@ -190,9 +281,9 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 
 __global__ void __launch_bounds__(256) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
     const DScene& S = P.S;
-    const uint32_t count = W.counters[in_q == 0 ? 0 : 1];
+    const uint32_t count = W.counters[CTR(in_q == 0 ? 0 : 1)];
     uint32_t* out_q = W.q_active[in_q ^ 1];
-    uint32_t* out_count = &W.counters[in_q == 0 ? 1 : 0];
+    uint32_t* out_count = &W.counters[CTR(in_q == 0 ? 1 : 0)];
     int err = 0;
     const uint32_t stride = gridDim.x * 256u;
     const uint32_t rounds = (count + stride - 1) / stride;
@@ -334,10 +425,13 @@ __global__ void __launch_bounds__(256) k_wf_shade(RenderParams P, WfBuffers W, i
                 push_active = alive || (ps & PS_DIRECT);        /* finished paths with a pending direct term come back once */
             }
         }
-        wave_push(push_active, p, out_q, out_count);
-        wave_push(push_closest, p, W.q_closest, &W.counters[2]);
-        wave_push(push_mis, p | WF_MIS_BIT, W.q_closest, &W.counters[2]);
-        wave_push(push_shadow, p, W.q_shadow, &W.counters[3]);
+        {
+            const bool pred[4] = {push_active, push_closest, push_mis, push_shadow};
+            const uint32_t val[4] = {p, p, p | WF_MIS_BIT, p};
+            uint32_t* const qs[4] = {out_q, W.q_closest, W.q_closest, W.q_shadow};
+            uint32_t* const cs[4] = {out_count, &W.counters[CTR(2)], &W.counters[CTR(2)], &W.counters[CTR(3)]};
+            block_push<4>(pred, val, qs, cs);
+        }
     }
     if (err) atomicCAS(&P.stats->error, 0, err);
 }
@@ -345,8 +439,12 @@ __global__ void __launch_bounds__(256) k_wf_shade(RenderParams P, WfBuffers W, i
 /* counters housekeeping between kernels (one tiny launch instead of host round trips) */
 __global__ void k_wf_reset(WfBuffers W, int mode, int in_q) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (mode == 0) { for (int i = 0; i < 8; i++) W.counters[i] = 0; }                       /* new pass */
-    else if (mode == 1) { W.counters[2] = 0; W.counters[3] = 0; W.counters[4] = 0; W.counters[5] = 0; W.counters[in_q == 0 ? 1 : 0] = 0; }   /* before shade */
+    if (mode == 0) {                                                                         /* new pass: generate fills both queues densely */
+        for (int i = 0; i < 8; i++) W.counters[CTR(i)] = 0;
+        W.counters[CTR(0)] = W.samples * W.valid_per_sample; W.counters[CTR(2)] = W.samples * W.valid_per_sample;
+    } else if (mode == 1) {                                                                  /* before shade */
+        W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(4)] = 0; W.counters[CTR(5)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0;
+    }
 }
 
 /* ------------------------------------------------------------------ accumulate: add_sample_to_tile in sample order */
@@ -438,16 +536,32 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh_o, n)) || (rc = wf_alloc(st, &W.sh_d, n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) ||
-        (rc = wf_alloc(st, &W.counters, 8))) return rc;
+        (rc = wf_alloc(st, &W.counters, 8 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
+}
+
+/* tuning knobs of k_wf_trace (env overrides are for experiments only) */
+static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(name); return v ? (uint32_t)atoi(v) : def; }
+
+static void launch_trace(bool any, bool count, bool spheres, unsigned grid, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
+                         const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
+    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 12), chunk_knob = knob("FTN_TRACE_CHUNK", 256);
+    /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
+    uint32_t chunk = chunk_knob;
+    const uint32_t waves = grid * 4u;
+    while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
+#define FTN_TR(A, C, Sp) hipLaunchKernelGGL((k_wf_trace<A, C, Sp>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk)
+    if (any) { if (count) { if (spheres) FTN_TR(true, true, true); else FTN_TR(true, true, false); } else { if (spheres) FTN_TR(true, false, true); else FTN_TR(true, false, false); } }
+    else { if (count) { if (spheres) FTN_TR(false, true, true); else FTN_TR(false, true, false); } else { if (spheres) FTN_TR(false, false, true); else FTN_TR(false, false, false); } }
+#undef FTN_TR
 }
 
 int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times) {
     if (!*state) {
         *state = new WavefrontState();
         for (int i = 0; i < 64; i++) { WF_TRY(hipEventCreate(&(*state)->ev[i])); (*state)->n_ev = i + 1; }
-        WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 8 * sizeof(uint32_t)));
+        WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 8 * 32 * sizeof(uint32_t)));
         hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
         (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
@@ -462,6 +576,9 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     S = std::min(S, total_samples);
     int rc = wf_reserve(st, (size_t)S * n_slots); if (rc) return rc;
     WfBuffers W = st->W;
+    const bool spheres = P.S.n_spheres != 0;
+    uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
+    W.valid_per_sample = valid;
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
@@ -488,22 +605,20 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
             if (ev_used + 2 > 64) { rc = flush_events(); if (rc) return rc; }
             WF_TRY(hipEventRecord(st->ev[ev_used], stream));
-            if (count) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(tg), dim3(256), lds, stream, P.S, W, W.q_closest, &W.counters[2], &W.counters[4], P.stats, 24u);
-            else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(tg), dim3(256), lds, stream, P.S, W, W.q_closest, &W.counters[2], &W.counters[4], P.stats, 24u);
+            launch_trace(false, count, spheres, tg, lds, stream, P, W, W.q_closest, &W.counters[CTR(2)], &W.counters[CTR(4)], 2 * W.n_paths);
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (W.n_paths + 255) / 256);
-                if (count) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(sg), dim3(256), lds, stream, P.S, W, W.q_shadow, &W.counters[3], &W.counters[5], P.stats, 24u);
-                else hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(sg), dim3(256), lds, stream, P.S, W, W.q_shadow, &W.counters[3], &W.counters[5], P.stats, 24u);
+                launch_trace(true, count, spheres, sg, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(5)], W.n_paths);
             }
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q);
             hipLaunchKernelGGL(k_wf_shade, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
             in_q ^= 1;
             if (it >= P.max_depth) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
-                WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 WF_TRY(hipStreamSynchronize(stream));
-                if (st->host_counters[in_q == 0 ? 0 : 1] == 0) break;
+                if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
             }
         }
         hipLaunchKernelGGL(k_wf_accumulate, dim3((n_slots + 255) / 256), dim3(256), 0, stream, P, W);
