@@ -81,21 +81,24 @@ __device__ inline DRay spawn_ray_to_hit(const DSurfHit& a, const DSurfHit& to) {
 /* ------------------------------------------------------------------ Bounds3f::intersect_test: bounds.rs:214-233
  * inv = 1/dir is the value the reference recomputes at every node. */
 __device__ inline bool slab_test(float4 nlo, float4 nhi, V3 o, V3 inv, float t_max) {
+    /* Branch-free form of the reference's loop with its three early `return None`s: the running t0/t1 of axis i only depend on
+     * axes <= i, so OR-ing the three `t0 > t1` tests gives the same boolean.  (With the early exits the compiler sinks the loads
+     * of the y/z bounds behind the x test: three dependent memory round trips per node instead of one.) */
     const float k = 1.0f + 2.0f * gamma_n(3);
-    float t0 = 0.0f, t1 = t_max;
-    float tn = (nlo.x - o.x) * inv.x, tf = (nhi.x - o.x) * inv.x;
-    if (tn > tf) { float s = tn; tn = tf; tf = s; }
-    tf *= k; t0 = fmax_(t0, tn); t1 = fmin_(t1, tf);
-    if (t0 > t1) return false;
-    tn = (nlo.y - o.y) * inv.y; tf = (nhi.y - o.y) * inv.y;
-    if (tn > tf) { float s = tn; tn = tf; tf = s; }
-    tf *= k; t0 = fmax_(t0, tn); t1 = fmin_(t1, tf);
-    if (t0 > t1) return false;
-    tn = (nlo.z - o.z) * inv.z; tf = (nhi.z - o.z) * inv.z;
-    if (tn > tf) { float s = tn; tn = tf; tf = s; }
-    tf *= k; t0 = fmax_(t0, tn); t1 = fmin_(t1, tf);
-    return !(t0 > t1);
+    float tnx = (nlo.x - o.x) * inv.x, tfx = (nhi.x - o.x) * inv.x;
+    float tny = (nlo.y - o.y) * inv.y, tfy = (nhi.y - o.y) * inv.y;
+    float tnz = (nlo.z - o.z) * inv.z, tfz = (nhi.z - o.z) * inv.z;
+    if (tnx > tfx) { float s = tnx; tnx = tfx; tfx = s; }
+    if (tny > tfy) { float s = tny; tny = tfy; tfy = s; }
+    if (tnz > tfz) { float s = tnz; tnz = tfz; tfz = s; }
+    tfx *= k; tfy *= k; tfz *= k;
+    const float t0x = fmax_(0.0f, tnx), t1x = fmin_(t_max, tfx);
+    const float t0y = fmax_(t0x, tny), t1y = fmin_(t1x, tfy);
+    const float t0z = fmax_(t0y, tnz), t1z = fmin_(t1y, tfz);
+    return !((t0x > t1x) | (t0y > t1y) | (t0z > t1z));
 }
+/* keeps a loaded float4 whole: stops the compiler from splitting / sinking its dword loads behind later branches */
+__device__ inline void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
 /* ------------------------------------------------------------------ Triangle::intersect, hit-test part: triangle.rs:176-268 */
 __device__ inline bool tri_hit(V3 o, V3 d, float t_max, V3 p0, V3 p1, V3 p2, float* t_out, float* b0o, float* b1o, float* b2o) {
@@ -228,7 +231,8 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
     const uint32_t neg = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
     int sp = 0; uint32_t cur = 0; bool found = false;
     for (;;) {
-        const float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
+        float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
+        pin4(nlo); pin4(nhi);
         if (COUNT) tc->nodes++;
         bool descend = false;
         if (slab_test(nlo, nhi, ray.o, inv, ray.t_max)) {
@@ -237,7 +241,8 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
                 const uint32_t n = meta & 0xffffu;
                 for (uint32_t i = 0; i < n; i++) {
                     const uint32_t prim = idx + i;
-                    const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                    float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                    pin4(g0); pin4(g1); pin4(g2);
                     if (COUNT) tc->prims++;
                     const uint32_t fl = __float_as_uint(g0.w);
                     float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool h;

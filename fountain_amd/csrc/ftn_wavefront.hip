@@ -138,8 +138,10 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     TravCount tc{0, 0};
     uint32_t mode = TM_IDLE;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
+    /* per-wave chunk: few queue-head atomics, but small enough that the tail spreads over all waves */
+    { uint32_t c = count / (gridDim.x * 4u * 16u); c &= ~63u; chunk = c < 64u ? 64u : (c > chunk ? chunk : c); }
     uint32_t rid = 0, cur = 0, neg = 0, lp = 0, lp_end = 0; int sp = 0;
-    V3 o, inv, dperm; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kx = 0, ky = 0, kz = 0;
+    V3 o, inv, dperm; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kz = 0;
     int hprim = -1; float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f; bool found = false;
     V3 dorig;   /* only the sphere path needs the unpermuted direction */
     for (;;) {
@@ -166,8 +168,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
                 /* Triangle::intersect's per-ray constants (triangle.rs:189-205): permutation and shear depend on the ray only */
-                kz = max_dimension(vabs(d)); kx = kz + 1; if (kx == 3) kx = 0; ky = kx + 1; if (ky == 3) ky = 0;
-                dperm = V3(d.get(kx), d.get(ky), d.get(kz));
+                kz = max_dimension(vabs(d));
+                { const int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1; dperm = V3(d.get(kx), d.get(ky), d.get(kz)); }
                 sx = -dperm.x / dperm.z; sy = -dperm.y / dperm.z; sz = 1.0f / dperm.z;
                 sp = 0; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
                 mode = TM_NODE;
@@ -184,7 +186,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
             /* ---- node step */
             if (mode == TM_NODE) {
-                const float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
+                float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
+                pin4(nlo); pin4(nhi);
                 if (COUNT) tc.nodes++;
                 bool pop = true;
                 if (slab_test(nlo, nhi, o, inv, t_max)) {
@@ -203,7 +206,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             /* ---- leaf step: one primitive per lane */
             if (mode == TM_LEAF) {
                 const uint32_t prim = lp;
-                const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) tc.prims++;
                 const uint32_t fl = __float_as_uint(g0.w);
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh = false;
@@ -212,11 +216,15 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                     hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
                 } else {
                     /* Triangle::intersect hit test (triangle.rs:183-268) with the per-ray constants hoisted */
-                    const V3 op(o.get(kx), o.get(ky), o.get(kz));
-                    V3 p0t(g0.x, g0.y, g0.z), p1t(g1.x, g1.y, g1.z), p2t(g2.x, g2.y, g2.z);
-                    p0t = V3(p0t.get(kx) - op.x, p0t.get(ky) - op.y, p0t.get(kz) - op.z);
-                    p1t = V3(p1t.get(kx) - op.x, p1t.get(ky) - op.y, p1t.get(kz) - op.z);
-                    p2t = V3(p2t.get(kx) - op.x, p2t.get(ky) - op.y, p2t.get(kz) - op.z);
+                    /* permute_point(p - o, kx, ky, kz) with (kx, ky, kz) = (kz+1, kz+2, kz) mod 3, as selects on registers */
+                    const bool k0 = kz == 0, k1 = kz == 1;
+#define FTN_PERM(v) V3(k0 ? (v).y : (k1 ? (v).z : (v).x), k0 ? (v).z : (k1 ? (v).x : (v).y), k0 ? (v).x : (k1 ? (v).y : (v).z))
+                    const V3 op = FTN_PERM(o);
+                    V3 p0t = FTN_PERM(g0), p1t = FTN_PERM(g1), p2t = FTN_PERM(g2);
+#undef FTN_PERM
+                    p0t = V3(p0t.x - op.x, p0t.y - op.y, p0t.z - op.z);
+                    p1t = V3(p1t.x - op.x, p1t.y - op.y, p1t.z - op.z);
+                    p2t = V3(p2t.x - op.x, p2t.y - op.y, p2t.z - op.z);
                     p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
                     p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
                     p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
@@ -546,7 +554,7 @@ static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(na
 
 static void launch_trace(bool any, bool count, bool spheres, unsigned grid, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
-    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 12), chunk_knob = knob("FTN_TRACE_CHUNK", 256);
+    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 6), chunk_knob = knob("FTN_TRACE_CHUNK", 256);
     /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
