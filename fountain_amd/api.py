@@ -81,7 +81,7 @@ def default_backend():
     global _default_backend
     if _default_backend is None:
         here = os.path.dirname(os.path.abspath(__file__))
-        _default_backend = Backend(os.path.join(here, "libfountain_hip.so"), "ftn_", False)
+        _default_backend = Backend(os.path.join(here, os.environ.get("FTN_LIB", "libfountain_hip.so")), "ftn_", False)
     return _default_backend
 
 

@@ -593,41 +593,41 @@ __device__ inline bool lobe_sample(const DLobe& L, V3 wo, V2 u, DScatter* o) {
 
 /* Bsdf::new + Material::compute_scattering_functions (src/material/ *.rs); roughness already mapped to alpha on the host.
  * Returns false for the configuration the reference panics on (specular glass with allow_multiple_lobes). */
+__device__ inline void add_lobe(DBsdf* B, const DLobe& L) { if (B->n == 0) B->lobe[0] = L; else B->lobe[1] = L; B->n++; }   /* static indices: stays in VGPRs */
+__device__ inline DLobe mk_lobe(uint32_t kind, Rgb r, uint32_t fresnel, float p0, float p1, float ei, float et, const ftn_material* m) {
+    DLobe L; L.kind = kind; L.fresnel = fresnel; L.r = r; L.p0 = p0; L.p1 = p1; L.ei = ei; L.et = et; L.m = m; return L;
+}
 __device__ inline bool make_bsdf(const ftn_material& m, const DSI& si, bool allow_multiple_lobes, DBsdf* B) {
     B->ns = si.shading_n; B->ng = si.hit.n;
     B->ss = normalize(si.s_dpdu);
     B->ts = normalize(cross(B->ns, B->ss));
     B->n = 0;
+    B->lobe[0] = mk_lobe(BX_LAMBERT, Rgb(0.0f), FR_NOOP, 0.0f, 0.0f, 1.0f, 1.0f, &m); B->lobe[1] = B->lobe[0];
     const Rgb a(m.a[0], m.a[1], m.a[2]), b(m.b[0], m.b[1], m.b[2]);
     switch (m.type) {
-        case FTN_MAT_MATTE: {
+        case FTN_MAT_MATTE: {                                  /* matte.rs:35-52; OrenNayar A/B precomputed in s1/s2 */
             Rgb r = clamp_positive(a);
-            if (!r.is_black()) {
-                DLobe& L = B->lobe[B->n++]; L.r = r; L.fresnel = FR_NOOP; L.m = &m;
-                if (m.s0 == 0.0f) L.kind = BX_LAMBERT; else { L.kind = BX_OREN; L.p0 = m.s1; L.p1 = m.s2; }   /* a, b precomputed */
-            }
+            if (!r.is_black()) add_lobe(B, mk_lobe(m.s0 == 0.0f ? BX_LAMBERT : BX_OREN, r, FR_NOOP, m.s1, m.s2, 1.0f, 1.0f, &m));
             return true;
         }
-        case FTN_MAT_METAL: {
-            DLobe& L = B->lobe[B->n++]; L.kind = BX_MF_R; L.r = Rgb(1.0f); L.p0 = m.s1; L.p1 = m.s2; L.fresnel = FR_COND; L.m = &m;
+        case FTN_MAT_METAL:                                     /* metal.rs:37-65 */
+            add_lobe(B, mk_lobe(BX_MF_R, Rgb(1.0f), FR_COND, m.s1, m.s2, 1.0f, 1.0f, &m));
             return true;
-        }
-        case FTN_MAT_MIRROR: {
+        case FTN_MAT_MIRROR: {                                  /* mirror.rs:21-30 */
             Rgb r = clamp_positive(a);
-            if (!r.is_black()) { DLobe& L = B->lobe[B->n++]; L.kind = BX_SPEC_R; L.r = r; L.fresnel = FR_NOOP; L.m = &m; }
+            if (!r.is_black()) add_lobe(B, mk_lobe(BX_SPEC_R, r, FR_NOOP, 0.0f, 0.0f, 1.0f, 1.0f, &m));
             return true;
         }
-        case FTN_MAT_PLASTIC: {
-            if (!a.is_black()) { DLobe& L = B->lobe[B->n++]; L.kind = BX_LAMBERT; L.r = a; L.fresnel = FR_NOOP; L.m = &m; }
-            if (!b.is_black()) { DLobe& L = B->lobe[B->n++]; L.kind = BX_MF_R; L.r = b; L.p0 = m.s1; L.p1 = m.s1; L.fresnel = FR_DIEL; L.ei = 1.5f; L.et = 1.0f; L.m = &m; }
+        case FTN_MAT_PLASTIC:                                   /* plastic.rs:24-48 */
+            if (!a.is_black()) add_lobe(B, mk_lobe(BX_LAMBERT, a, FR_NOOP, 0.0f, 0.0f, 1.0f, 1.0f, &m));
+            if (!b.is_black()) add_lobe(B, mk_lobe(BX_MF_R, b, FR_DIEL, m.s1, m.s1, 1.5f, 1.0f, &m));
             return true;
-        }
-        default: {   /* glass */
+        default: {                                              /* glass.rs:51-93 */
             Rgb r = clamp_positive(a), t = clamp_positive(b);
             bool is_spec = m.s1 == 0.0f && m.s2 == 0.0f;
             if (is_spec && allow_multiple_lobes) return false;
-            if (!r.is_black()) { DLobe& L = B->lobe[B->n++]; L.kind = is_spec ? BX_SPEC_R : BX_MF_R; L.r = r; L.p0 = m.s1; L.p1 = m.s2; L.fresnel = FR_DIEL; L.ei = 1.0f; L.et = m.s0; L.m = &m; }
-            if (!t.is_black()) { DLobe& L = B->lobe[B->n++]; L.kind = is_spec ? BX_SPEC_T : BX_MF_T; L.r = t; L.p0 = m.s1; L.p1 = m.s2; L.fresnel = FR_DIEL; L.ei = 1.0f; L.et = m.s0; L.m = &m; }
+            if (!r.is_black()) add_lobe(B, mk_lobe(is_spec ? BX_SPEC_R : BX_MF_R, r, FR_DIEL, m.s1, m.s2, 1.0f, m.s0, &m));
+            if (!t.is_black()) add_lobe(B, mk_lobe(is_spec ? BX_SPEC_T : BX_MF_T, t, FR_DIEL, m.s1, m.s2, 1.0f, m.s0, &m));
             return true;
         }
     }
@@ -636,13 +636,20 @@ __device__ inline V3 to_local(const DBsdf& B, V3 v) { return V3(dot(v, B.ss), do
 __device__ inline V3 to_world(const DBsdf& B, V3 v) {
     return V3(B.ss.x * v.x + B.ts.x * v.y + B.ns.x * v.z, B.ss.y * v.x + B.ts.y * v.y + B.ns.y * v.z, B.ss.z * v.x + B.ts.z * v.y + B.ns.z * v.z);
 }
-__device__ inline int bsdf_num(const DBsdf& B, uint32_t flags) { int n = 0; for (int i = 0; i < B.n; i++) n += lobe_matches(B.lobe[i].kind, flags) ? 1 : 0; return n; }
+__device__ inline int bsdf_num(const DBsdf& B, uint32_t flags) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) if (i < B.n) n += lobe_matches(B.lobe[i].kind, flags) ? 1 : 0;
+    return n;
+}
 __device__ inline Rgb bsdf_sum_f(const DBsdf& B, V3 wo, V3 wi, bool refl, uint32_t flags) {
     Rgb sum(0.0f);
-    for (int i = 0; i < B.n; i++) {
-        const uint32_t t = lobe_type(B.lobe[i].kind);
-        if ((flags & t) != t) continue;
-        if ((refl && (t & T_REFL)) || (!refl && (t & T_TRANS))) sum = sum + lobe_f(B.lobe[i], wo, wi);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (i < B.n) {
+            const uint32_t t = lobe_type(B.lobe[i].kind);
+            if ((flags & t) == t && ((refl && (t & T_REFL)) || (!refl && (t & T_TRANS)))) sum = sum + lobe_f(B.lobe[i], wo, wi);
+        }
     }
     return sum;
 }
@@ -656,26 +663,30 @@ __device__ inline float bsdf_pdf(const DBsdf& B, V3 wo_w, V3 wi_w, uint32_t flag
     V3 wo = to_local(B, wo_w), wi = to_local(B, wi_w);
     if (wo.z == 0.0f) return 0.0f;
     float nm = (float)bsdf_num(B, flags), pdf = 0.0f;
-    for (int i = 0; i < B.n; i++) if (lobe_matches(B.lobe[i].kind, flags)) pdf = pdf + lobe_pdf(B.lobe[i], wo, wi);
+#pragma unroll
+    for (int i = 0; i < 2; i++) if (i < B.n && lobe_matches(B.lobe[i].kind, flags)) pdf = pdf + lobe_pdf(B.lobe[i], wo, wi);
     return nm > 0.0f ? pdf / nm : 0.0f;
 }
 __device__ inline bool bsdf_sample(const DBsdf& B, V3 wo_w, V2 u, uint32_t flags, DScatter* out) {   /* bsdf.rs:85-129 */
     float mc = (float)bsdf_num(B, flags);
     if (mc == 0.0f) return false;
     int comp = (int)f2usize(fmin_(floorf(u.x * mc), mc - 1.0f));
-    int sel = -1, cnt = comp;
-    for (int i = 0; i < B.n; i++) if (lobe_matches(B.lobe[i].kind, flags)) { if (cnt-- == 0) { sel = i; break; } }
+    /* the comp-th matching lobe; with at most two lobes: lobe 0 if it matches and comp == 0, else lobe 1 */
+    const bool m0 = B.n > 0 && lobe_matches(B.lobe[0].kind, flags);
+    const int sel = (m0 && comp == 0) ? 0 : 1;
     V2 ur(u.x * mc - (float)comp, u.y);
     V3 wo = to_local(B, wo_w);
     DScatter s;
-    if (!lobe_sample(B.lobe[sel], wo, ur, &s)) return false;
+    const DLobe Ls = sel == 0 ? B.lobe[0] : B.lobe[1];
+    if (!lobe_sample(Ls, wo, ur, &s)) return false;
     float pdf = s.pdf; Rgb f = s.f;
     if (pdf == 0.0f) return false;
     V3 wi_w = to_world(B, s.wi);
-    const bool spec = (lobe_type(B.lobe[sel].kind) & T_SPECULAR) != 0;
+    const bool spec = (lobe_type(Ls.kind) & T_SPECULAR) != 0;
     if (!spec && mc > 1.0f) {
         float extra = 0.0f;
-        for (int i = 0; i < B.n; i++) if (i != sel && lobe_matches(B.lobe[i].kind, flags)) extra = extra + lobe_pdf(B.lobe[i], wo, s.wi);
+#pragma unroll
+        for (int i = 0; i < 2; i++) if (i < B.n && i != sel && lobe_matches(B.lobe[i].kind, flags)) extra = extra + lobe_pdf(B.lobe[i], wo, s.wi);
         pdf += extra;
     }
     if (mc > 1.0f) pdf /= mc;

@@ -44,6 +44,7 @@ struct WfBuffers {
     float4 *rad;                /* L.xyz, bits(light index of the pending direct term) */
     ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
+    float2* p_film;             /* the camera sample's film position (for the in-order film add) */
     uint32_t *q_active[2], *q_closest, *q_shadow;
     uint32_t* counters;         /* one 128-byte line each (CTR(i) = 32*i): 0 active A, 1 active B, 2 closest, 3 shadow, 4 head closest, 5 head shadow */
     uint32_t valid_per_sample;  /* camera samples per spp pass (sum of the tiles' pixel counts) */
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
         W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
+        W.p_film[i] = make_float2(p_film.x, p_film.y);
         const uint32_t qi = s * W.valid_per_sample + tile.valid_off + (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
         W.q_active[0][qi] = i;
         W.q_closest[qi] = i;
@@ -129,7 +131,7 @@ enum : uint32_t { TM_IDLE = 0, TM_NODE = 1, TM_LEAF = 2 };
 
 template <bool ANY, bool COUNT, bool SPHERES>
 __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
-                                                  DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk) {
+                                                  DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t node_burst) {
     extern __shared__ uint32_t lds_stack[];
     const LdsStack st{lds_stack + threadIdx.x, 256u};
     const uint32_t count = *count_ptr;
@@ -184,23 +186,25 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         if ((m_node | m_leaf) == 0) { if (exhausted) break; else continue; }
         bool finish = false;
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
-            /* ---- node step */
-            if (mode == TM_NODE) {
-                float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
-                pin4(nlo); pin4(nhi);
-                if (COUNT) tc.nodes++;
-                bool pop = true;
-                if (slab_test(nlo, nhi, o, inv, t_max)) {
-                    const uint32_t idx = __float_as_uint(nlo.w), meta = __float_as_uint(nhi.w);
-                    if (meta >> 24) { lp = idx; lp_end = idx + (meta & 0xffffu); mode = TM_LEAF; pop = false; }
-                    else {
-                        const uint32_t axis = (meta >> 16) & 3u;
-                        if ((neg >> axis) & 1u) { st.push(sp++, cur + 1); cur = idx; }
-                        else { st.push(sp++, idx); cur = cur + 1; }
-                        pop = false;
+            /* ---- node steps: `node_burst` of them per control round (lanes that reach a leaf or finish sit out the rest) */
+            for (uint32_t burst = 0; burst < node_burst; burst++) {
+                if (mode == TM_NODE && !finish) {
+                    float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
+                    pin4(nlo); pin4(nhi);
+                    if (COUNT) tc.nodes++;
+                    bool pop = true;
+                    if (slab_test(nlo, nhi, o, inv, t_max)) {
+                        const uint32_t idx = __float_as_uint(nlo.w), meta = __float_as_uint(nhi.w);
+                        if (meta >> 24) { lp = idx; lp_end = idx + (meta & 0xffffu); mode = TM_LEAF; pop = false; }
+                        else {
+                            const uint32_t axis = (meta >> 16) & 3u;
+                            if ((neg >> axis) & 1u) { st.push(sp++, cur + 1); cur = idx; }
+                            else { st.push(sp++, idx); cur = cur + 1; }
+                            pop = false;
+                        }
                     }
+                    if (pop) { if (sp == 0) finish = true; else cur = st.pop(--sp); }
                 }
-                if (pop) { if (sp == 0) finish = true; else cur = st.pop(--sp); }
             }
         } else {
             /* ---- leaf step: one primitive per lane */
@@ -287,7 +291,10 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
     const float4 h = W.hit[r]; DHit o; o.t = h.x; o.b0 = h.y; o.b1 = h.z; o.b2 = h.w; o.prim = W.hit_prim[r]; return o;
 }
 
-__global__ void __launch_bounds__(256) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
+#ifndef FTN_SHADE_MIN_WAVES
+#define FTN_SHADE_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
     const DScene& S = P.S;
     const uint32_t count = W.counters[CTR(in_q == 0 ? 0 : 1)];
     uint32_t* out_q = W.q_active[in_q ^ 1];
@@ -495,9 +502,8 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
                 const float4 l = W.rad[s * W.n_slots + slot];
                 Rgb L(l.x, l.y, l.z);
                 if (L.has_nans()) err = FTN_ERR_NAN_RADIANCE;
-                Rng rng; rng.seed(indexed_key(P.seed, px, py, W.first_sample + s));
-                V2 j = rng.next2();
-                wf_film_add(P, F, V2((float)px + j.x, (float)py + j.y), L, in_crop ? px : (-2147483647), py, &acc, &spill);
+                const float2 pf = W.p_film[s * W.n_slots + slot];
+                wf_film_add(P, F, V2(pf.x, pf.y), L, in_crop ? px : (-2147483647), py, &acc, &spill);
                 cam++;
             }
             if (in_crop) P.accA[ai] = acc;
@@ -515,7 +521,7 @@ const char* wavefront_error() { return g_wf_err.c_str(); }
 
 struct WavefrontState {
     size_t cap_paths = 0;
-    void* mem[24]; int n_mem = 0;
+    void* mem[32]; int n_mem = 0;
     WfBuffers W;
     hipEvent_t ev[64]; int n_ev = 0;
     uint32_t* host_counters = nullptr;    /* pinned */
@@ -542,7 +548,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     WfBuffers& W = st->W; int rc;
     if ((rc = wf_alloc(st, &W.ray_o, 2 * n)) || (rc = wf_alloc(st, &W.ray_d, 2 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
         (rc = wf_alloc(st, &W.sh_o, n)) || (rc = wf_alloc(st, &W.sh_d, n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
-        (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
+        (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) ||
         (rc = wf_alloc(st, &W.counters, 8 * 32))) return rc;
     st->cap_paths = n;
@@ -554,12 +560,12 @@ static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(na
 
 static void launch_trace(bool any, bool count, bool spheres, unsigned grid, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
-    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 6), chunk_knob = knob("FTN_TRACE_CHUNK", 256);
+    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 256), node_burst = knob("FTN_TRACE_BURST", 8);
     /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
-#define FTN_TR(A, C, Sp) hipLaunchKernelGGL((k_wf_trace<A, C, Sp>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk)
+#define FTN_TR(A, C, Sp) hipLaunchKernelGGL((k_wf_trace<A, C, Sp>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst)
     if (any) { if (count) { if (spheres) FTN_TR(true, true, true); else FTN_TR(true, true, false); } else { if (spheres) FTN_TR(true, false, true); else FTN_TR(true, false, false); } }
     else { if (count) { if (spheres) FTN_TR(false, true, true); else FTN_TR(false, true, false); } else { if (spheres) FTN_TR(false, false, true); else FTN_TR(false, false, false); } }
 #undef FTN_TR

@@ -19,9 +19,8 @@ def run(env):
     rays = best["rays_closest"] + best["rays_any"]
     print("%-60s total %.2f ms  trace(closest) %.2f ms  -> %.0f Mrays/s" % (env, best["kernel_ms"], best["trace_ms"], rays / best["kernel_ms"] / 1e3), flush=True)
 run({})
-for refill in (8, 16, 32, 48):
-    run({"FTN_TRACE_REFILL": refill, "FTN_TRACE_LEAF_BATCH": 12, "FTN_TRACE_CHUNK": 256})
-for lb in (1, 4, 8, 16, 24, 32):
-    run({"FTN_TRACE_REFILL": 16, "FTN_TRACE_LEAF_BATCH": lb, "FTN_TRACE_CHUNK": 256})
-for ch in (64, 128, 512, 1024):
-    run({"FTN_TRACE_REFILL": 16, "FTN_TRACE_LEAF_BATCH": 12, "FTN_TRACE_CHUNK": ch})
+for burst in (4, 6, 8, 12, 16):
+    for lb in (2, 4, 8):
+        run({"FTN_TRACE_BURST": burst, "FTN_TRACE_LEAF_BATCH": lb, "FTN_TRACE_REFILL": 16})
+for refill in (8, 24, 32):
+    run({"FTN_TRACE_BURST": 8, "FTN_TRACE_LEAF_BATCH": 4, "FTN_TRACE_REFILL": refill})
