@@ -23,6 +23,8 @@
 
 namespace ftn {
 
+#define FTN_DEV_NOINLINE __device__ inline   /* out-of-line variants were measured slower (see detmath.h) */
+
 enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u };
 enum : uint32_t { LK_POINT = 0, LK_DISTANT = 1, LK_INFINITE = 2, LK_AREA = 3 };
 
@@ -161,7 +163,7 @@ __device__ inline bool tri_uv_degenerate_reject(const DScene& S, int prim, V3 p0
 __device__ inline bool sphere_clipped(const DSphere& s, V3 p, float phi) {
     return (s.z_min > -s.radius && p.z < s.z_min) || (s.z_max < s.radius && p.z > s.z_max) || phi > s.phi_max;
 }
-__device__ inline bool sphere_intersect(const DSphere& s, const DRay& wr, float* t_out, DSI* si) {
+FTN_DEV_NOINLINE bool sphere_intersect(const DSphere& s, const DRay& wr, float* t_out, DSI* si) {
     V3 o_err, d_err;
     V3 ot = m4_point_exact_to_err(s.w2o, wr.o, &o_err);      /* Ray::tf_exact_to_err transform.rs:287-300 */
     V3 dt_ = m4_vector_exact_to_err(s.w2o, wr.d, &d_err);
@@ -279,7 +281,7 @@ __device__ inline void load_tri(const DScene& S, int prim, V3* p0, V3* p1, V3* p
     *p0 = V3(g0.x, g0.y, g0.z); *p1 = V3(g1.x, g1.y, g1.z); *p2 = V3(g2.x, g2.y, g2.z); *flags = __float_as_uint(g0.w);
 }
 /* triangle.rs:270-393 */
-__device__ inline void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, float time, DSI* si) {
+FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, float time, DSI* si) {
     V3 p0, p1, p2; uint32_t fl; load_tri(S, h.prim, &p0, &p1, &p2, &fl);
     const uint4 vi = S.prim_info[2 * h.prim + 1];
     const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
@@ -335,7 +337,7 @@ __device__ inline bool make_interaction(const DScene& S, const DHit& h, const DR
 }
 
 /* ------------------------------------------------------------------ shapes as emitters: shapes/mod.rs:39-66 */
-__device__ inline DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
+FTN_DEV_NOINLINE DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
     const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
     const uint32_t fl = __float_as_uint(g0.w);
     DSurfHit h;
@@ -368,7 +370,7 @@ __device__ inline DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
     return h;
 }
 /* Shape::pdf_from_ref: intersects the light's own shape, bypassing the BVH (shapes/mod.rs:55-66) */
-__device__ inline float shape_pdf_from_ref(const DScene& S, int prim, float area, const DSurfHit& ref, V3 wi) {
+FTN_DEV_NOINLINE float shape_pdf_from_ref(const DScene& S, int prim, float area, const DSurfHit& ref, V3 wi) {
     DRay ray = spawn_ray(ref, wi);
     const float4 g0 = S.geom[3 * prim];
     V3 hp, hn;
@@ -425,7 +427,7 @@ __device__ inline float fresnel_dielectric(float ci, float eta_i, float eta_t) {
     float rper = ((eta_i * ci) - (eta_t * ct)) / ((eta_i * ci) + (eta_t * ct));
     return (rpar * rpar + rper * rper) / 2.0f;
 }
-__device__ inline Rgb fresnel_conductor(float ci, Rgb eta_i, Rgb eta_t, Rgb k) {   /* fresnel.rs:25-48 */
+FTN_DEV_NOINLINE Rgb fresnel_conductor(float ci, Rgb eta_i, Rgb eta_t, Rgb k) {   /* fresnel.rs:25-48 */
     ci = clampf(ci, -1.0f, 1.0f);
     Rgb eta = eta_t / eta_i, eta_k = k / eta_i;
     float c2 = ci * ci, s2 = 1.0f - c2;
@@ -472,7 +474,7 @@ __device__ inline V3 tr_sample_wh(float ax, float ay, V3 wo, V2 u) {
     } else {
         phi = ftn_det::atanf_det(ay / ax * ftn_det::tanf_det(2.0f * FTN_PI * u.y + 0.5f * FTN_PI));
         if (u.y > 0.5f) phi += FTN_PI;
-        float sp = ftn_det::sinf_det(phi), cp = ftn_det::cosf_det(phi);
+        float sp, cp; ftn_det::sincosf_det(phi, &sp, &cp);
         float alpha2 = 1.0f / ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay));
         float tt2 = alpha2 * u.x / (1.0f - u.x);
         ct = 1.0f / sqrtf(1.0f + tt2);
@@ -492,7 +494,7 @@ __device__ inline bool refract(V3 wi, V3 n, float eta, V3* wt) {                
 }
 __device__ inline float mt_eta(const DLobe& L, V3 wo) { return wo.z > 0.0f ? L.et / L.ei : L.ei / L.et; }   /* get_eta :378-380 */
 
-__device__ inline Rgb lobe_f(const DLobe& L, V3 wo, V3 wi) {
+FTN_DEV_NOINLINE Rgb lobe_f(const DLobe& L, V3 wo, V3 wi) {
     switch (L.kind) {
         case BX_LAMBERT: return L.r * FTN_INV_PI;
         case BX_OREN: {
@@ -526,7 +528,7 @@ __device__ inline Rgb lobe_f(const DLobe& L, V3 wo, V3 wi) {
         }
     }
 }
-__device__ inline float lobe_pdf(const DLobe& L, V3 wo, V3 wi) {
+FTN_DEV_NOINLINE float lobe_pdf(const DLobe& L, V3 wo, V3 wi) {
     switch (L.kind) {
         case BX_LAMBERT: case BX_OREN: return same_hemisphere(wo, wi) ? fabsf(wi.z) * FTN_INV_PI : 0.0f;
         case BX_SPEC_R: case BX_SPEC_T: return 0.0f;
@@ -546,7 +548,7 @@ __device__ inline float lobe_pdf(const DLobe& L, V3 wo, V3 wi) {
     }
 }
 struct DScatter { Rgb f; V3 wi; float pdf; uint32_t type; };
-__device__ inline bool lobe_sample(const DLobe& L, V3 wo, V2 u, DScatter* o) {
+FTN_DEV_NOINLINE bool lobe_sample(const DLobe& L, V3 wo, V2 u, DScatter* o) {
     o->type = lobe_type(L.kind);
     switch (L.kind) {
         case BX_LAMBERT: case BX_OREN: {
@@ -729,7 +731,7 @@ __device__ inline void dist1d_sample(const float* func, const float* cdf, float 
     *x = ((float)i + du) / (float)n;
     *idx = i;
 }
-__device__ inline Rgb light_Le_env(const DLight& L, V3 dir) {    /* infinite.rs:156-164 */
+FTN_DEV_NOINLINE Rgb light_Le_env(const DLight& L, V3 dir) {    /* infinite.rs:156-164 */
     V3 w = normalize(m4_vector(L.w2l, dir));
     V2 st(spherical_phi(w) * (1.0f / (2.0f * FTN_PI)), spherical_theta(w) * FTN_INV_PI);
     return env_lookup(L, st);
@@ -744,7 +746,7 @@ __device__ inline Rgb area_Le(const DLight& L, V3 n, V3 w) {     /* diffuse.rs:4
     return dot(n, w) > 0.0f ? Rgb(L.rgb[0], L.rgb[1], L.rgb[2]) : Rgb(0.0f);
 }
 struct DLiSample { Rgb radiance; V3 wi; float pdf; DSurfHit p1; };
-__device__ inline DLiSample light_sample(const DScene& S, const DLight& L, const DSurfHit& ref, V2 u) {
+FTN_DEV_NOINLINE DLiSample light_sample(const DScene& S, const DLight& L, const DSurfHit& ref, V2 u) {
     DLiSample s;
     switch (L.kind) {
         case LK_POINT: {
@@ -766,8 +768,9 @@ __device__ inline DLiSample light_sample(const DScene& S, const DLight& L, const
             dist1d_sample(L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), L.cond_integral[vi], L.nu, u.x, &d0, &pdf0, &ui);
             float map_pdf = pdf0 * pdf1;
             float theta = d1 * FTN_PI, phi = d0 * 2.0f * FTN_PI;
-            float sth = ftn_det::sinf_det(theta);
-            s.wi = m4_vector(L.l2w, V3(sth * ftn_det::cosf_det(phi), sth * ftn_det::sinf_det(phi), ftn_det::cosf_det(theta)));
+            float sth, cth, sph, cph;
+            ftn_det::sincosf_det(theta, &sth, &cth); ftn_det::sincosf_det(phi, &sph, &cph);
+            s.wi = m4_vector(L.l2w, V3(sth * cph, sth * sph, cth));
             s.pdf = (sth == 0.0f) ? 0.0f : map_pdf / (2.0f * FTN_PI * FTN_PI * sth);
             if (map_pdf == 0.0f) s.pdf = 0.0f;                                   /* reference: unimplemented!() */
             s.p1.p = ref.p + s.wi * (2.0f * L.world_radius); s.p1.p_err = V3(); s.p1.time = ref.time; s.p1.n = V3();
@@ -784,7 +787,7 @@ __device__ inline DLiSample light_sample(const DScene& S, const DLight& L, const
         }
     }
 }
-__device__ inline float light_pdf(const DScene& S, const DLight& L, const DSurfHit& ref, V3 wi) {
+FTN_DEV_NOINLINE float light_pdf(const DScene& S, const DLight& L, const DSurfHit& ref, V3 wi) {
     if (L.kind == LK_AREA) return shape_pdf_from_ref(S, L.prim, L.area, ref, wi);
     if (L.kind != LK_INFINITE) return 0.0f;
     V3 w = m4_vector(L.w2l, wi);                                                 /* infinite.rs:142-154 */

@@ -109,7 +109,7 @@ FTN_HD V3 offset_ray_origin(V3 p, V3 p_err, V3 n, V3 dir) {
 FTN_HD float spherical_theta(V3 v) { return ftn_det::acosf_det(clampf(v.z, -1.0f, 1.0f)); }
 FTN_HD float spherical_phi(V3 v) { float p = ftn_det::atan2f_det(v.y, v.x); return p < 0.0f ? p + (2.0f * FTN_PI) : p; }
 /* math.rs:74-80 */
-FTN_HD V3 spherical_direction(float st, float ct, float phi) { return V3(st * ftn_det::cosf_det(phi), st * ftn_det::sinf_det(phi), ct); }
+FTN_HD V3 spherical_direction(float st, float ct, float phi) { float s, c; ftn_det::sincosf_det(phi, &s, &c); return V3(st * c, st * s, ct); }
 
 /* ---- Spectrum (RGB f32): spectrum/mod.rs */
 struct Rgb {
@@ -232,7 +232,8 @@ FTN_HD V2 concentric_sample_disk(V2 u) {
     float theta, r;
     if (fabsf(ox) > fabsf(oy)) { theta = FTN_PI_4 * (oy / ox); r = ox; }
     else { theta = FTN_PI_2 - FTN_PI_4 * (ox / oy); r = oy; }
-    return V2(r * ftn_det::cosf_det(theta), r * ftn_det::sinf_det(theta));
+    float s, c; ftn_det::sincosf_det(theta, &s, &c);
+    return V2(r * c, r * s);
 }
 FTN_HD V3 cosine_sample_hemisphere(V2 u) {
     V2 d = concentric_sample_disk(u);
@@ -242,7 +243,8 @@ FTN_HD V3 uniform_sample_sphere(V2 u) {
     float z = 1.0f - 2.0f * u.x;
     float r = sqrtf(fmax_(1.0f - z * z, 0.0f));
     float phi = 2.0f * FTN_PI * u.y;
-    return V3(r * ftn_det::cosf_det(phi), r * ftn_det::sinf_det(phi), z);
+    float s, c; ftn_det::sincosf_det(phi, &s, &c);
+    return V3(r * c, r * s, z);
 }
 FTN_HD V2 uniform_sample_triangle(V2 u) { float s = sqrtf(u.x); return V2(1.0f - s, u.y * s); }
 FTN_HD float power_heuristic(float f_pdf, float g_pdf) {   /* nf = ng = 1 (sampling.rs:53-57) */
