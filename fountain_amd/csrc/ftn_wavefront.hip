@@ -46,6 +46,9 @@ struct WfBuffers {
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
     float2* p_film;             /* the camera sample's film position (for the in-order film add) */
     uint32_t *q_active[2], *q_closest, *q_shadow;
+    uint32_t* q_sorted;         /* the active queue grouped by shading class (material-sorted shading) */
+    uint32_t* cls;              /* per-class path counts, one 128-byte line each (CTR(k)) */
+    uint32_t seg_cap;           /* capacity of one class segment of q_sorted */
     uint32_t* counters;         /* one 128-byte line each (CTR(i) = 32*i): 0 active A, 1 active B, 2 closest, 3 shadow, 4 head closest, 5 head shadow */
     uint32_t valid_per_sample;  /* camera samples per spp pass (sum of the tiles' pixel counts) */
 };
@@ -286,6 +289,56 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
 }
 
+/* ------------------------------------------------------------------ material-sorted shading: group the active queue by shading class
+ * class 0: finished paths that only need their pending direct term resolved; 1: alive, ray escaped or depth limit reached
+ * (emission / environment only); 2..: alive hit, by material type (2 + FTN_MAT_*), 7: primitive without material.
+ * Two passes (count, scatter) with block-level ballots; class segments start at multiples of 256 so that every shade
+ * workgroup sees a single class and its branches on hit/material are wave-uniform. */
+#define WF_NCLASS 8
+__device__ inline uint32_t wf_class_of(const RenderParams& P, const WfBuffers& W, uint32_t p) {
+    const uint32_t ps = __float_as_uint(W.beta[p].w);
+    if (!(ps & PS_ALIVE)) return 0u;
+    const int prim = W.hit_prim[p];
+    if (prim < 0 || (ps & PS_BOUNCE_MASK) >= P.max_depth) return 1u;
+    const int mat = (int)P.S.prim_info[2 * prim].x;
+    if (mat < 0) return 7u;
+    return 2u + P.S.materials[mat].type;
+}
+/* ONE pass: each class owns a segment of `seg_cap` slots in q_sorted (worst case: every path in one class), filled with one
+ * global atomic per workgroup and class.  The shade kernel derives the 256-aligned virtual layout from the 8 counts itself. */
+__global__ void __launch_bounds__(256) k_wf_classify(RenderParams P, WfBuffers W, int in_q) {
+    __shared__ uint32_t s_cnt[WF_NCLASS][4];
+    __shared__ uint32_t s_base[WF_NCLASS];
+    const uint32_t count = W.counters[CTR(in_q == 0 ? 0 : 1)];
+    const uint32_t stride = gridDim.x * 256u, rounds = (count + stride - 1) / stride;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t qi = round * stride + blockIdx.x * 256u + threadIdx.x;
+        const bool have = qi < count;
+        uint32_t p = 0, c = WF_NCLASS;
+        if (have) { p = W.q_active[in_q][qi]; c = wf_class_of(P, W, p); }
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < WF_NCLASS; k++) {
+            const unsigned long long m = __ballot(c == (uint32_t)k);
+            if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(m);
+            if (c == (uint32_t)k) mine = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < WF_NCLASS) {
+            const uint32_t k = threadIdx.x, tot = s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+            s_base[k] = tot ? atomicAdd(&W.cls[CTR(k)], tot) : 0u;
+        }
+        __syncthreads();
+        if (have) {
+            uint32_t off = s_base[c];
+            for (uint32_t w2 = 0; w2 < wave; w2++) off += s_cnt[c][w2];
+            W.q_sorted[(size_t)c * W.seg_cap + off + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = p;
+        }
+        __syncthreads();
+    }
+}
+
 /* ------------------------------------------------------------------ shade */
 __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
     const float4 h = W.hit[r]; DHit o; o.t = h.x; o.b0 = h.y; o.b1 = h.z; o.b2 = h.w; o.prim = W.hit_prim[r]; return o;
@@ -296,7 +349,12 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 #endif
 __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
     const DScene& S = P.S;
-    const uint32_t count = W.counters[CTR(in_q == 0 ? 0 : 1)];
+    /* virtual, 256-aligned concatenation of the class segments: a workgroup never straddles two classes */
+    uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
+    cbase[0] = 0;
+#pragma unroll
+    for (int k = 0; k < WF_NCLASS; k++) { ccnt[k] = W.cls[CTR(k)]; cbase[k + 1] = cbase[k] + ((ccnt[k] + 255u) & ~255u); }
+    const uint32_t count = cbase[WF_NCLASS];
     uint32_t* out_q = W.q_active[in_q ^ 1];
     uint32_t* out_count = &W.counters[CTR(in_q == 0 ? 1 : 0)];
     int err = 0;
@@ -304,11 +362,19 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
     const uint32_t rounds = (count + stride - 1) / stride;
     for (uint32_t round = 0; round < rounds; round++) {
         const uint32_t qi = round * stride + blockIdx.x * 256u + threadIdx.x;
-        const bool have = qi < count;
+        bool have = false;
+        uint32_t sorted_idx = 0;
+        if (qi < count) {                                  /* which class segment does this slot belong to, and is it occupied? */
+            uint32_t c = 0, cb = 0, cc = ccnt[0];
+#pragma unroll
+            for (int k = 1; k < WF_NCLASS; k++) if (qi >= cbase[k]) { c = (uint32_t)k; cb = cbase[k]; cc = ccnt[k]; }
+            have = qi - cb < cc;
+            sorted_idx = c * W.seg_cap + (qi - cb);
+        }
         bool push_active = false, push_closest = false, push_mis = false, push_shadow = false;
         uint32_t p = 0;
         if (have) {
-            p = W.q_active[in_q][qi];
+            p = W.q_sorted[sorted_idx];
             float4 bq = W.beta[p], lq = W.rad[p];
             Rgb beta(bq.x, bq.y, bq.z), L(lq.x, lq.y, lq.z);
             uint32_t ps = __float_as_uint(bq.w);
@@ -452,13 +518,16 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
 }
 
 /* counters housekeeping between kernels (one tiny launch instead of host round trips) */
-__global__ void k_wf_reset(WfBuffers W, int mode, int in_q) {
+__global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {                                                                         /* new pass: generate fills both queues densely */
         for (int i = 0; i < 8; i++) W.counters[CTR(i)] = 0;
         W.counters[CTR(0)] = W.samples * W.valid_per_sample; W.counters[CTR(2)] = W.samples * W.valid_per_sample;
+        stats->camera_samples += (unsigned long long)W.samples * W.valid_per_sample;
     } else if (mode == 1) {                                                                  /* before shade */
         W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(4)] = 0; W.counters[CTR(5)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0;
+    } else if (mode == 2) {                                                                  /* before classify */
+        for (int i = 0; i < WF_NCLASS; i++) W.cls[CTR(i)] = 0;
     }
 }
 
@@ -509,9 +578,8 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
             if (in_crop) P.accA[ai] = acc;
         }
     }
-    unsigned long long c = cam, sp = spill;
-    for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); sp += __shfl_down(sp, off, 64); }
-    if (lane_id() == 0) { if (c) atomicAdd(&P.stats->camera_samples, c); if (sp) atomicAdd(&P.stats->spill_samples, sp); }
+    (void)cam;                                               /* camera_samples is known in closed form: added once by k_wf_reset */
+    if (spill) atomicAdd(&P.stats->spill_samples, (unsigned long long)spill);       /* rare */
     if (err) atomicCAS(&P.stats->error, 0, err);
 }
 
@@ -549,7 +617,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     if ((rc = wf_alloc(st, &W.ray_o, 2 * n)) || (rc = wf_alloc(st, &W.ray_d, 2 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
         (rc = wf_alloc(st, &W.sh_o, n)) || (rc = wf_alloc(st, &W.sh_d, n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
-        (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) ||
+        (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
         (rc = wf_alloc(st, &W.counters, 8 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
@@ -610,8 +678,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     };
     for (uint32_t s0 = 0; s0 < total_samples; s0 += S) {
         const uint32_t Sp = std::min(S, total_samples - s0);
-        W.n_slots = n_slots; W.samples = Sp; W.n_paths = Sp * n_slots; W.first_sample = P.first_sample + s0;
-        hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 0, 0);
+        W.n_slots = n_slots; W.samples = Sp; W.n_paths = Sp * n_slots; W.first_sample = P.first_sample + s0; W.seg_cap = (uint32_t)st->cap_paths;
+        hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 0, 0, P.stats);
         hipLaunchKernelGGL(k_wf_generate, dim3((W.n_paths + 255) / 256), dim3(256), 0, stream, P, W);
         int in_q = 0;
         const uint32_t max_iter = P.max_depth + 2 + 64;     /* +64: null-material pass-throughs do not count as bounces */
@@ -626,7 +694,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (W.n_paths + 255) / 256);
                 launch_trace(true, count, spheres, sg, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(5)], W.n_paths);
             }
-            hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q);
+            {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
+                const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
+                hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
+                hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
+            }
+            hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
             hipLaunchKernelGGL(k_wf_shade, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
             in_q ^= 1;
             if (it >= P.max_depth) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
