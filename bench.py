@@ -157,19 +157,25 @@ def cpu_baseline(desc, cam, film, n_cpu_tiles, n_tiles):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:                                               # a cgroup CPU quota (not visible in the affinity mask) bounds the useful thread count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(round(float(quota) / float(period)))))
+    except Exception:
+        pass
     cores = max(1, min(cores, int(os.environ.get("FTN_BENCH_CPU_THREADS", "64"))))
-    f = Film(orc, (film.desc.full_resolution[0], film.desc.full_resolution[1]))
     si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
     smp = RandomSampler(4096, 0, indexed=True, first_sample=0, sample_count=1)
-    # calibrate on a few tiles, then size the sample for ~15 s of wall time
-    probe = max(cores, 16)
-    stride = max(1, n_tiles // probe)
-    st = si.render_parallel(scene, f, smp, tiles=(stride // 2, stride, probe), n_threads=cores)
-    rate = probe / max(st["kernel_ms"] * 1e-3, 1e-3)
-    n_cpu_tiles = int(min(n_tiles, max(n_cpu_tiles, rate * 15.0)))
-    stride = max(1, n_tiles // n_cpu_tiles)
-    f = Film(orc, (film.desc.full_resolution[0], film.desc.full_resolution[1]))
-    st = si.render_parallel(scene, f, smp, tiles=(stride // 2, stride, n_cpu_tiles), n_threads=cores)
+    res = (film.desc.full_resolution[0], film.desc.full_resolution[1])
+    # grow the tile sample until one run takes about 10-20 s of wall time
+    n_cpu_tiles = min(n_tiles, max(n_cpu_tiles, 8 * cores))
+    for _ in range(4):
+        stride = max(1, n_tiles // n_cpu_tiles)
+        st = si.render_parallel(scene, Film(orc, res), smp, tiles=(stride // 2, stride, n_cpu_tiles), n_threads=cores)
+        secs = st["kernel_ms"] * 1e-3
+        if secs >= 8.0 or n_cpu_tiles >= n_tiles:
+            break
+        n_cpu_tiles = int(min(n_tiles, n_cpu_tiles * min(8.0, 14.0 / max(secs, 1e-3))))
     rays = st["rays_closest"] + st["rays_any"]
     secs = st["kernel_ms"] * 1e-3
     return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
