@@ -135,6 +135,14 @@ def main():
                          "launches_per_step": int(launches_per_step), "nodes_per_ray": round(nodes_c / max(cst["rays_closest"], 1), 2),
                          "prims_per_ray": round(prims_c / max(cst["rays_closest"], 1), 3)},
         }
+        # HBM-side traffic of the same kernel from PMC counters (collected offline with rocprofv3, see profiles/r01_traffic.json)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("workload") == "copies=%d,res=%d,spp_per_step=%d" % (args.copies, args.res, spp_per_step):
+                out["roofline"]["traffic"] = int(tj["traffic_bytes_per_launch"])
+                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam, film, args.cpu_tiles, n_tiles)
         print(json.dumps(out), flush=True)
