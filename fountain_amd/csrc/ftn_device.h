@@ -25,7 +25,7 @@ namespace ftn {
 
 #define FTN_DEV_NOINLINE __device__ inline   /* out-of-line variants were measured slower (see detmath.h) */
 
-enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u };
+enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u, GF_LEAF_END = 16u /* last primitive of its BVH leaf */ };
 enum : uint32_t { LK_POINT = 0, LK_DISTANT = 1, LK_INFINITE = 2, LK_AREA = 3 };
 
 struct DSphere {
@@ -57,6 +57,12 @@ struct DScene {
     const DSphere* spheres; const ftn_material* materials; const DLight* lights;
     uint32_t n_nodes, n_prims, n_lights, n_inf_lights, n_spheres, _pad;
     const uint32_t* inf_lights;             /* indices of infinite lights (environment_emitted_radiance sums all lights) */
+    /* second view of the same BVH for the fast traversal kernels: one 64-byte record per INTERIOR node holding both children's boxes
+     *   {c0.bmin, bits(meta0)} {c0.bmax, bits(ptr0)} {c1.bmin, bits(meta1)} {c1.bmax, bits(ptr1)}
+     * meta: bit 31 = child is a leaf; meta0 bits 16..17 = split axis of this node. ptr: record index of an interior child, first primitive of a leaf */
+    const float4* fat;
+    float root_lo[3], root_hi[3];
+    uint32_t root_is_leaf, n_fat;
 };
 
 struct DCamera {

@@ -340,13 +340,13 @@ struct ftn_scene {
     int device = 0;
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
-    DevBuf<float4> nodes, geom; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
+    DevBuf<float4> nodes, geom, fat; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
     DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc;
     /* render work buffers (grow-only, reused across calls) */
     DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
     WavefrontState* wf = nullptr;
     ~ftn_scene() {
-        nodes.release(); geom.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
+        nodes.release(); geom.release(); fat.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
         accA.release(); accB.release(); accC.release(); tiles.release(); stats.release();
         wavefront_destroy(wf);
@@ -362,6 +362,25 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         nodes[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], ftn_det::u2f(n.idx));
         nodes[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], ftn_det::u2f((uint32_t)n.n_prims | ((uint32_t)n.axis << 16) | ((uint32_t)n.is_leaf << 24)));
     }
+    /* fat records (see DScene::fat): one per interior node, numbered in DFS order */
+    std::vector<uint32_t> fat_id(hs.nodes.size(), 0xffffffffu);
+    uint32_t n_fat = 0;
+    for (size_t i = 0; i < hs.nodes.size(); i++) if (!hs.nodes[i].is_leaf) fat_id[i] = n_fat++;
+    std::vector<float4> fat(4 * (size_t)n_fat);
+    std::vector<uint8_t> leaf_end(np, 0);
+    for (size_t i = 0; i < hs.nodes.size(); i++) {
+        const ftn_bvh_node& n = hs.nodes[i];
+        if (n.is_leaf) { if (n.n_prims) leaf_end[n.idx + n.n_prims - 1] = 1; continue; }
+        const size_t ch[2] = {i + 1, (size_t)n.idx};
+        for (int k = 0; k < 2; k++) {
+            const ftn_bvh_node& c = hs.nodes[ch[k]];
+            uint32_t meta = c.is_leaf ? 0x80000000u : 0u;
+            if (k == 0) meta |= (uint32_t)n.axis << 16;
+            const uint32_t ptr = c.is_leaf ? c.idx : fat_id[ch[k]];
+            fat[4 * (size_t)fat_id[i] + 2 * k] = make_float4(c.bmin[0], c.bmin[1], c.bmin[2], ftn_det::u2f(meta));
+            fat[4 * (size_t)fat_id[i] + 2 * k + 1] = make_float4(c.bmax[0], c.bmax[1], c.bmax[2], ftn_det::u2f(ptr));
+        }
+    }
     std::vector<int> prim_light(np, -1);
     for (size_t l = 0; l < hs.light_prim.size(); l++) if (hs.light_prim[l] >= 0) prim_light[hs.light_prim[l]] = (int)l;
     std::vector<float4> geom(3 * np); std::vector<uint4> info(2 * np);
@@ -369,7 +388,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         const ftn_prim& p = d->prims[hs.order[i]];
         uint32_t fl = 0;
         if (p.shape_kind == FTN_SHAPE_SPHERE) {
-            fl = GF_KIND_SPHERE;
+            fl = GF_KIND_SPHERE | (leaf_end[i] ? GF_LEAF_END : 0u);
             geom[3 * i] = make_float4(0, 0, 0, ftn_det::u2f(fl)); geom[3 * i + 1] = make_float4(0, 0, 0, ftn_det::u2f(p.shape_index)); geom[3 * i + 2] = make_float4(0, 0, 0, 0);
             info[2 * i + 1] = make_uint4(0, 0, 0, p.shape_index);
         } else {
@@ -377,6 +396,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if (m.has_normals && d->N) fl |= GF_HAS_NORMALS;
             if (m.has_uvs && d->UV) fl |= GF_HAS_UVS;
             if (m.flip_normals) fl |= GF_FLIP;
+            if (leaf_end[i]) fl |= GF_LEAF_END;
             const uint32_t* vi = d->tri_indices + 3 * (size_t)p.shape_index;
             const float* P = d->P;
             geom[3 * i] = make_float4(P[3 * vi[0]], P[3 * vi[0] + 1], P[3 * vi[0] + 2], ftn_det::u2f(fl));
@@ -389,6 +409,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     int rc;
     if ((rc = sc->nodes.upload(nodes.data(), nodes.size()))) return rc;
     if ((rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
+    if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc;
     if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
     if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
     if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
@@ -477,6 +498,8 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
+    D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
+    for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
     sc->stack_entries = std::max<uint32_t>(hs.max_depth, 1u);
     if ((rc = sc->stats.alloc_zero(1))) return rc;
     return FTN_OK;

@@ -120,6 +120,62 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
     }
 }
 
+/* one primitive of a leaf against the ray: Triangle::intersect's hit test (triangle.rs:183-268) with the per-ray permutation
+ * (kz) and shear (sx, sy, sz) hoisted, or Sphere::intersect */
+template <bool SPHERES>
+__device__ inline bool prim_hit(const DScene& S, uint32_t prim, float4 g0, float4 g1, float4 g2, V3 o, V3 dorig, float t_max, int kz, float sx, float sy, float sz,
+                                float* t_out, float* b0o, float* b1o, float* b2o) {
+    const uint32_t fl = __float_as_uint(g0.w);
+    float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh = false;
+    if (SPHERES && (fl & GF_KIND_SPHERE)) {
+        DRay r; r.o = o; r.d = dorig; r.t_max = t_max; r.time = 0.0f;
+        hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
+    } else {
+        /* Triangle::intersect hit test (triangle.rs:183-268) with the per-ray constants hoisted */
+        /* permute_point(p - o, kx, ky, kz) with (kx, ky, kz) = (kz+1, kz+2, kz) mod 3, as selects on registers */
+        const bool k0 = kz == 0, k1 = kz == 1;
+#define FTN_PERM(v) V3(k0 ? (v).y : (k1 ? (v).z : (v).x), k0 ? (v).z : (k1 ? (v).x : (v).y), k0 ? (v).x : (k1 ? (v).y : (v).z))
+        const V3 op = FTN_PERM(o);
+        V3 p0t = FTN_PERM(g0), p1t = FTN_PERM(g1), p2t = FTN_PERM(g2);
+#undef FTN_PERM
+        p0t = V3(p0t.x - op.x, p0t.y - op.y, p0t.z - op.z);
+        p1t = V3(p1t.x - op.x, p1t.y - op.y, p1t.z - op.z);
+        p2t = V3(p2t.x - op.x, p2t.y - op.y, p2t.z - op.z);
+        p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+        p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+        p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+        float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+        float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+        float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+        if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+            e0 = (float)((double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x);
+            e1 = (float)((double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x);
+            e2 = (float)((double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x);
+        }
+        const float det = e0 + e1 + e2;
+        if (!(sign_pos(e0) != sign_pos(e1) || sign_pos(e1) != sign_pos(e2)) && det != 0.0f) {
+            p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+            const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+            if (!((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)))) {
+                const float inv_det = 1.0f / det;
+                b0 = e0 * inv_det; b1 = e1 * inv_det; b2 = e2 * inv_det; t = t_scaled * inv_det;
+                const float max_zt = fmax_(fmax_(fabsf(p0t.z), fabsf(p1t.z)), fabsf(p2t.z));
+                const float delta_z = gamma_n(3) * max_zt;
+                const float max_xt = fmax_(fmax_(fabsf(p0t.x), fabsf(p1t.x)), fabsf(p2t.x));
+                const float max_yt = fmax_(fmax_(fabsf(p0t.y), fabsf(p1t.y)), fabsf(p2t.y));
+                const float delta_x = gamma_n(5) * (max_xt + max_zt), delta_y = gamma_n(5) * (max_yt + max_zt);
+                const float delta_e = 2.0f * (gamma_n(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+                const float max_e = fmax_(fmax_(fabsf(e0), fabsf(e1)), fabsf(e2));
+                const float delta_t = 3.0f * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+                hh = !(t <= delta_t);
+                if (hh && (fl & GF_HAS_UVS) && tri_uv_degenerate_reject(S, (int)prim, V3(g0.x, g0.y, g0.z), V3(g1.x, g1.y, g1.z), V3(g2.x, g2.y, g2.z))) hh = false;
+            }
+        }
+    }
+    *t_out = t; *b0o = b0; *b1o = b1; *b2o = b2;
+    return hh;
+}
+
 /* ------------------------------------------------------------------ trace
  * Per lane: mode 0 = needs a ray, 1 = at a BVH node, 2 = holds a leaf whose primitives are still to be tested.
  * A wave alternates between two cheap, convergent bodies instead of running the (long) triangle test for the two or three
@@ -216,53 +272,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) tc.prims++;
-                const uint32_t fl = __float_as_uint(g0.w);
-                float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh = false;
-                if (SPHERES && (fl & GF_KIND_SPHERE)) {
-                    DRay r; r.o = o; r.d = dorig; r.t_max = t_max; r.time = 0.0f;
-                    hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
-                } else {
-                    /* Triangle::intersect hit test (triangle.rs:183-268) with the per-ray constants hoisted */
-                    /* permute_point(p - o, kx, ky, kz) with (kx, ky, kz) = (kz+1, kz+2, kz) mod 3, as selects on registers */
-                    const bool k0 = kz == 0, k1 = kz == 1;
-#define FTN_PERM(v) V3(k0 ? (v).y : (k1 ? (v).z : (v).x), k0 ? (v).z : (k1 ? (v).x : (v).y), k0 ? (v).x : (k1 ? (v).y : (v).z))
-                    const V3 op = FTN_PERM(o);
-                    V3 p0t = FTN_PERM(g0), p1t = FTN_PERM(g1), p2t = FTN_PERM(g2);
-#undef FTN_PERM
-                    p0t = V3(p0t.x - op.x, p0t.y - op.y, p0t.z - op.z);
-                    p1t = V3(p1t.x - op.x, p1t.y - op.y, p1t.z - op.z);
-                    p2t = V3(p2t.x - op.x, p2t.y - op.y, p2t.z - op.z);
-                    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
-                    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
-                    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
-                    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
-                    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
-                    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
-                    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
-                        e0 = (float)((double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x);
-                        e1 = (float)((double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x);
-                        e2 = (float)((double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x);
-                    }
-                    const float det = e0 + e1 + e2;
-                    if (!(sign_pos(e0) != sign_pos(e1) || sign_pos(e1) != sign_pos(e2)) && det != 0.0f) {
-                        p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
-                        const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-                        if (!((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)))) {
-                            const float inv_det = 1.0f / det;
-                            b0 = e0 * inv_det; b1 = e1 * inv_det; b2 = e2 * inv_det; t = t_scaled * inv_det;
-                            const float max_zt = fmax_(fmax_(fabsf(p0t.z), fabsf(p1t.z)), fabsf(p2t.z));
-                            const float delta_z = gamma_n(3) * max_zt;
-                            const float max_xt = fmax_(fmax_(fabsf(p0t.x), fabsf(p1t.x)), fabsf(p2t.x));
-                            const float max_yt = fmax_(fmax_(fabsf(p0t.y), fabsf(p1t.y)), fabsf(p2t.y));
-                            const float delta_x = gamma_n(5) * (max_xt + max_zt), delta_y = gamma_n(5) * (max_yt + max_zt);
-                            const float delta_e = 2.0f * (gamma_n(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
-                            const float max_e = fmax_(fmax_(fabsf(e0), fabsf(e1)), fabsf(e2));
-                            const float delta_t = 3.0f * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
-                            hh = !(t <= delta_t);
-                            if (hh && (fl & GF_HAS_UVS) && tri_uv_degenerate_reject(S, (int)prim, V3(g0.x, g0.y, g0.z), V3(g1.x, g1.y, g1.z), V3(g2.x, g2.y, g2.z))) hh = false;
-                        }
-                    }
-                }
+                float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                const bool hh = prim_hit<SPHERES>(S, prim, g0, g1, g2, o, dorig, t_max, kz, sx, sy, sz, &t, &b0, &b1, &b2);
                 if (hh) { found = true; t_max = t; hprim = (int)prim; hb0 = b0; hb1 = b1; hb2 = b2; }
                 lp++;
                 if (ANY && hh) finish = true;
@@ -284,6 +295,165 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         if (lane == 0) {
             if (n) atomicAdd(&stats->nodes_visited, n); if (p) atomicAdd(&stats->prims_tested, p);
             if (ANY) { if (n) atomicAdd(&stats->nodes_any, n); if (p) atomicAdd(&stats->prims_any, p); }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
+}
+
+/* ------------------------------------------------------------------ trace, fast variant: 64-byte records with both children's boxes
+ *
+ * k_wf_trace fetches every visited node, including the ones whose box test fails, and every fetch of a 32-byte node pulls a
+ * 128-byte line from HBM.  Here a lane sits on an INTERIOR node that has already passed its box test and reads one 64-byte
+ * record with both children's boxes (DScene::fat): children that fail are never fetched.
+ *
+ * The primitives tested, their order and every t_max update are exactly those of bvh.rs:160-266:
+ *   - near child (by dir_is_neg[axis]): its slab test runs now, with the current t_max - the reference runs the same test at
+ *     this point (it visits the near child next and nothing happens in between);
+ *   - far child: the reference tests its box when it is popped, with the t_max of that moment.  The slab test is
+ *         fail  <=>  t0 > min(t_max, F),   t0 = max(0, near-plane distances),  F = min(far-plane distances * (1+2 gamma(3)))
+ *     (the per-axis early exits of bounds.rs:214-233 are equivalent to this single comparison because the running t0 only grows
+ *     and the running t1 only shrinks; fmaxf/fminf ignore NaNs exactly like f32::max/min).  t0 and F do not depend on t_max.
+ *     So: if t0 > F or t0 > t_max now, the later test fails too (t_max only shrinks) and the child is dropped; otherwise
+ *     (child, t0) is pushed and the popped entry is culled iff t0 > t_max then - the same boolean the reference computes.
+ * Stack entry: {child, t0} in LDS ([level][lane], two planes); the sign bit of t0 (t0 >= 0) marks a leaf child.
+ * Leaf primitives are walked until the GF_LEAF_END flag.  Used when traffic counters are off; k_wf_trace remains the
+ * reference-order kernel that tallies nodes/primitives for the roofline's algorithmic bytes. */
+struct SlabOut { bool hit; float t0; };
+__device__ inline SlabOut slab_test2(float4 lo, float4 hi, V3 o, V3 inv, float t_max) {
+    const float k = 1.0f + 2.0f * gamma_n(3);
+    float tnx = (lo.x - o.x) * inv.x, tfx = (hi.x - o.x) * inv.x;
+    float tny = (lo.y - o.y) * inv.y, tfy = (hi.y - o.y) * inv.y;
+    float tnz = (lo.z - o.z) * inv.z, tfz = (hi.z - o.z) * inv.z;
+    if (tnx > tfx) { float s = tnx; tnx = tfx; tfx = s; }
+    if (tny > tfy) { float s = tny; tny = tfy; tfy = s; }
+    if (tnz > tfz) { float s = tnz; tnz = tfz; tfz = s; }
+    tfx *= k; tfy *= k; tfz *= k;
+    const float t0x = fmax_(0.0f, tnx), t1x = fmin_(t_max, tfx);
+    const float t0y = fmax_(t0x, tny), t1y = fmin_(t1x, tfy);
+    const float t0z = fmax_(t0y, tnz), t1z = fmin_(t1y, tfz);
+    SlabOut r; r.hit = !((t0x > t1x) | (t0y > t1y) | (t0z > t1z)); r.t0 = t0z;
+    return r;
+}
+
+template <bool ANY, bool SPHERES>
+__global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
+                                                      DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t node_burst, uint32_t stack_entries) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* const st_idx = lds_stack + threadIdx.x;                              /* [level][lane] */
+    float* const st_t0 = reinterpret_cast<float*>(lds_stack + stack_entries * 256u) + threadIdx.x;
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = lane_id();
+    const uint32_t np = W.n_paths;
+    uint32_t mode = TM_IDLE;
+    uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
+    { uint32_t c = count / (gridDim.x * 4u * 16u); c &= ~63u; chunk = c < 64u ? 64u : (c > chunk ? chunk : c); }
+    uint32_t rid = 0, cur = 0, neg = 0, lp = 0; int sp = 0;
+    V3 o, inv; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kz = 0;
+    int hprim = -1; float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f; bool found = false;
+    V3 dorig;
+    const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f), rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
+    for (;;) {
+        const unsigned long long idle = __ballot(mode == TM_IDLE);
+        if (!exhausted && (uint32_t)__popcll(idle) >= refill) {
+            const uint32_t need = (uint32_t)__popcll(idle);
+            if (chunk_next == chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, chunk);
+                base = __shfl(base, 0, 64);
+                chunk_next = base; chunk_end = base + chunk;
+                if (chunk_next >= count) { exhausted = true; chunk_end = chunk_next; }
+                else if (chunk_end > count) chunk_end = count;
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (mode == TM_IDLE && rank < avail) {
+                rid = queue[chunk_next + rank];
+                const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
+                const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
+                o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
+                if (SPHERES) dorig = d;
+                inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+                kz = max_dimension(vabs(d));
+                { const int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1; const V3 dp(d.get(kx), d.get(ky), d.get(kz)); sx = -dp.x / dp.z; sy = -dp.y / dp.z; sz = 1.0f / dp.z; }
+                sp = 0; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
+                /* the root's own box test (bvh.rs:174-176) */
+                const bool root_hit = S.n_nodes != 0 && slab_test(rlo, rhi, o, inv, t_max);
+                if (!root_hit) {
+                    if (ANY) W.occluded[rid] = 0; else { W.hit[r] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[r] = -1; }
+                    mode = TM_IDLE;
+                } else if (S.root_is_leaf) { lp = 0; mode = TM_LEAF; }
+                else mode = TM_NODE;
+            }
+            chunk_next += (need < avail ? need : avail);
+        }
+        const unsigned long long m_node = __ballot(mode == TM_NODE), m_leaf = __ballot(mode == TM_LEAF);
+        if ((m_node | m_leaf) == 0) { if (exhausted) break; else continue; }
+        bool finish = false, need_pop = false;
+        if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
+            for (uint32_t burst = 0; burst < node_burst; burst++) {
+                if (mode == TM_NODE && !finish) {
+                    float4 f0 = S.fat[4 * (size_t)cur], f1 = S.fat[4 * (size_t)cur + 1], f2 = S.fat[4 * (size_t)cur + 2], f3 = S.fat[4 * (size_t)cur + 3];
+                    pin4(f0); pin4(f1); pin4(f2); pin4(f3);
+                    const uint32_t axis = (__float_as_uint(f0.w) >> 16) & 3u;
+                    const bool swap = ((neg >> axis) & 1u) != 0;                  /* dir_is_neg[axis]: second child first */
+                    const float4 nlo = swap ? f2 : f0, nhi = swap ? f3 : f1, flo = swap ? f0 : f2, fhi = swap ? f1 : f3;
+                    const SlabOut hn = slab_test2(nlo, nhi, o, inv, t_max);
+                    const SlabOut hf = slab_test2(flo, fhi, o, inv, t_max);
+                    if (hf.hit) {                                                 /* keep the far child for later, with its entry distance */
+                        const bool leaf = (__float_as_uint(flo.w) >> 31) != 0;
+                        st_idx[sp * 256] = __float_as_uint(fhi.w);
+                        st_t0[sp * 256] = leaf ? -hf.t0 : hf.t0;
+                        sp++;
+                    }
+                    if (hn.hit) {
+                        if (__float_as_uint(nlo.w) >> 31) { lp = __float_as_uint(nhi.w); mode = TM_LEAF; }
+                        else cur = __float_as_uint(nhi.w);
+                    } else need_pop = true;
+                    /* pop: drop entries whose box the ray no longer reaches (t0 > t_max) */
+                    while (need_pop) {
+                        if (sp == 0) { finish = true; need_pop = false; break; }
+                        --sp;
+                        const float e = st_t0[sp * 256];
+                        const uint32_t id = st_idx[sp * 256];
+                        if (!(fabsf(e) > t_max)) {
+                            need_pop = false;
+                            if (ftn_det::f2u(e) >> 31) { lp = id; mode = TM_LEAF; } else cur = id;
+                        }
+                    }
+                }
+            }
+        } else {
+            if (mode == TM_LEAF) {
+                const uint32_t prim = lp;
+                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                pin4(g0); pin4(g1); pin4(g2);
+                float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                const bool hh = prim_hit<SPHERES>(S, prim, g0, g1, g2, o, dorig, t_max, kz, sx, sy, sz, &t, &b0, &b1, &b2);
+                if (hh) { found = true; t_max = t; hprim = (int)prim; hb0 = b0; hb1 = b1; hb2 = b2; }
+                if (ANY && hh) finish = true;
+                else if (__float_as_uint(g0.w) & GF_LEAF_END) {
+                    bool popping = true;
+                    while (popping) {
+                        if (sp == 0) { finish = true; break; }
+                        --sp;
+                        const float e = st_t0[sp * 256];
+                        const uint32_t id = st_idx[sp * 256];
+                        if (!(fabsf(e) > t_max)) {
+                            popping = false;
+                            if (ftn_det::f2u(e) >> 31) { lp = id; mode = TM_LEAF; } else { cur = id; mode = TM_NODE; }
+                        }
+                    }
+                } else lp++;
+            }
+        }
+        if (finish) {
+            if (ANY) W.occluded[rid] = found ? 1 : 0;
+            else {
+                const uint32_t r = (rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid;
+                W.hit[r] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[r] = hprim;
+            }
+            mode = TM_IDLE;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
@@ -626,13 +796,25 @@ static int wf_reserve(WavefrontState* st, size_t n) {
 /* tuning knobs of k_wf_trace (env overrides are for experiments only) */
 static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(name); return v ? (uint32_t)atoi(v) : def; }
 
-static void launch_trace(bool any, bool count, bool spheres, unsigned grid, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
+static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int n_cu, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
     const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 256), node_burst = knob("FTN_TRACE_BURST", 8);
     /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
+    if (!count && knob("FTN_TRACE_FAT", 0)) {      /* measured slower on MI355X: kept as an exact alternative */
+        const size_t lds2 = 2 * lds;                                                   /* {child, t0} per level */
+        const uint32_t depth = (uint32_t)(lds / (256 * sizeof(uint32_t)));
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds2, 1)));
+        const unsigned g2 = std::min<unsigned>(grid, (unsigned)n_cu * per_cu);
+#define FTN_TF(A, Sp) if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_wf_trace_fat<A, Sp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        hipLaunchKernelGGL((k_wf_trace_fat<A, Sp>), dim3(g2), dim3(256), lds2, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst, depth)
+        if (any) { if (spheres) { FTN_TF(true, true); } else { FTN_TF(true, false); } } else { if (spheres) { FTN_TF(false, true); } else { FTN_TF(false, false); } }
+#undef FTN_TF
+        return;
+    }
+    lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
 #define FTN_TR(A, C, Sp) hipLaunchKernelGGL((k_wf_trace<A, C, Sp>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst)
     if (any) { if (count) { if (spheres) FTN_TR(true, true, true); else FTN_TR(true, true, false); } else { if (spheres) FTN_TR(true, false, true); else FTN_TR(true, false, false); } }
     else { if (count) { if (spheres) FTN_TR(false, true, true); else FTN_TR(false, true, false); } else { if (spheres) FTN_TR(false, false, true); else FTN_TR(false, false, false); } }
@@ -687,12 +869,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
             if (ev_used + 2 > 64) { rc = flush_events(); if (rc) return rc; }
             WF_TRY(hipEventRecord(st->ev[ev_used], stream));
-            launch_trace(false, count, spheres, tg, lds, stream, P, W, W.q_closest, &W.counters[CTR(2)], &W.counters[CTR(4)], 2 * W.n_paths);
+            launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, W.q_closest, &W.counters[CTR(2)], &W.counters[CTR(4)], 2 * W.n_paths);
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (W.n_paths + 255) / 256);
-                launch_trace(true, count, spheres, sg, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(5)], W.n_paths);
+                launch_trace(true, count, spheres, sg, st->n_cu, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(5)], W.n_paths);
             }
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);

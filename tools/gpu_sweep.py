@@ -18,9 +18,10 @@ def run(env):
         if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
     rays = best["rays_closest"] + best["rays_any"]
     print("%-60s total %.2f ms  trace(closest) %.2f ms  -> %.0f Mrays/s" % (env, best["kernel_ms"], best["trace_ms"], rays / best["kernel_ms"] / 1e3), flush=True)
-run({})
-for burst in (4, 6, 8, 12, 16):
+run({"FTN_TRACE_FAT": 0})
+run({"FTN_TRACE_FAT": 1})
+for burst in (2, 4, 8):
     for lb in (2, 4, 8):
-        run({"FTN_TRACE_BURST": burst, "FTN_TRACE_LEAF_BATCH": lb, "FTN_TRACE_REFILL": 16})
-for refill in (8, 24, 32):
-    run({"FTN_TRACE_BURST": 8, "FTN_TRACE_LEAF_BATCH": 4, "FTN_TRACE_REFILL": refill})
+        run({"FTN_TRACE_FAT": 1, "FTN_TRACE_BURST": burst, "FTN_TRACE_LEAF_BATCH": lb, "FTN_TRACE_REFILL": 16})
+run({"FTN_TRACE_FAT": 1, "FTN_TRACE_BURST": 4, "FTN_TRACE_LEAF_BATCH": 2, "FTN_TRACE_REFILL": 8})
+run({"FTN_TRACE_FAT": 1, "FTN_TRACE_BURST": 4, "FTN_TRACE_LEAF_BATCH": 2, "FTN_TRACE_REFILL": 32})
