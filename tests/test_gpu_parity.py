@@ -222,6 +222,38 @@ def test_furnace_256_energy(gpu):
     assert np.abs(rgb - (2.0 - 2.0 ** -5)).max() < 2e-2
 
 
+def _tile_subset_parity(gpu, orc_det, make, spp, tiles, pipeline=WAVE):
+    out = []
+    for be in (gpu, orc_det):
+        b, cam, res = make(be)
+        sc = b.create_scene()
+        film = Film(be, res)
+        si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+        kw = dict(pipeline=pipeline) if be is gpu else {}
+        st = si.render_parallel(sc, film, RandomSampler(spp, 0, indexed=True), tiles=tiles, **kw)
+        out.append((film.pixels, st))
+    (px, st), (pxo, sto) = out
+    assert_film_equal(px, pxo, st["spill_samples"], "tile subset")
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and st["camera_samples"] == sto["camera_samples"]
+    return px, st
+
+
+def test_config3_full_resolution_tile_subset(gpu, orc_det):
+    """BASELINE config 3 (rounded_cube.ply + env map, 1024x1024) at full resolution: 24 tiles spread over the film vs the oracle"""
+    px, st = _tile_subset_parity(gpu, orc_det, lambda be: scenes.rounded_cube_env(be, res=1024, env_n=512), 8, (37, 171, 24))
+    assert st["camera_samples"] == 24 * 256 * 8 and (px[..., 3] > 0).sum() >= 24 * 256
+
+
+def test_config4_like_full_resolution_tile_subset(gpu, orc_det):
+    """BASELINE config 4 shape: mesh copies with Trowbridge-Reitz metal, image env light, thin-lens depth of field at 1920x1080
+    (68 tile rows, the last one clipped to 8 pixels): 20 tiles including clipped ones vs the oracle"""
+    make = lambda be: scenes.instanced_cubes(be, n_copies=46, res=(1920, 1080), env_n=256, lens_radius=0.4)
+    n_tiles = Film(gpu, (1920, 1080)).tile_count()
+    assert n_tiles == 120 * 68
+    px, st = _tile_subset_parity(gpu, orc_det, make, 4, (n_tiles - 120 * 2 - 7, 13, 20))     # the last two tile rows
+    assert 0 < st["camera_samples"] < 20 * 256 * 4                                           # some tiles are 16x8
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_specular_glass_reports_unsupported(gpu):
     b = SceneBuilder(gpu)
