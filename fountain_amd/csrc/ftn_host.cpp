@@ -17,6 +17,10 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <functional>
+#include <cstdlib>
 
 using namespace ftn;
 
@@ -201,16 +205,20 @@ static Aabb aabb_empty() { Aabb b; for (int i = 0; i < 3; i++) { b.lo[i] = kFmax
 static void aabb_join_point(Aabb& b, V3 p) { b.lo[0] = fmin_(b.lo[0], p.x); b.lo[1] = fmin_(b.lo[1], p.y); b.lo[2] = fmin_(b.lo[2], p.z); b.hi[0] = fmax_(b.hi[0], p.x); b.hi[1] = fmax_(b.hi[1], p.y); b.hi[2] = fmax_(b.hi[2], p.z); }
 
 struct BvhBuilder {
-    const std::vector<Aabb>& bounds; std::vector<float> centroid;   /* 3 per prim */
-    std::vector<uint32_t> order;                                     /* permutation being partitioned */
+    const std::vector<Aabb>& bounds;
+    std::vector<float> own_centroid; std::vector<uint32_t> own_order;
+    std::vector<float>& centroid;                                    /* 3 per prim */
+    std::vector<uint32_t>& order;                                    /* permutation being partitioned */
     std::vector<ftn_bvh_node> nodes; std::vector<uint32_t> leaf_order; uint32_t max_depth = 0;
-    explicit BvhBuilder(const std::vector<Aabb>& b) : bounds(b) {
+    size_t leaf_base = 0;                                            /* global position of this builder's first leaf primitive */
+    /* sub-builder over a range of a parent's arrays (parallel build) */
+    BvhBuilder(const std::vector<Aabb>& b, std::vector<float>& c, std::vector<uint32_t>& o, size_t base) : bounds(b), centroid(c), order(o), leaf_base(base) {}
+    explicit BvhBuilder(const std::vector<Aabb>& b) : bounds(b), centroid(own_centroid), order(own_order) {
         size_t n = b.size(); centroid.resize(3 * n); order.resize(n);
         for (size_t i = 0; i < n; i++) {
             order[i] = (uint32_t)i;
             for (int k = 0; k < 3; k++) centroid[3 * i + k] = b[i].lo[k] + ((b[i].hi[k] - b[i].lo[k]) / 2.0f);   /* Bounds3::centroid bounds.rs:160-162 */
         }
-        nodes.reserve(2 * n); leaf_order.reserve(n);
     }
     void build(size_t lo, size_t hi, uint32_t depth) {               /* recursive_build :66-120 + flatten_tree :133-158 */
         if (depth > max_depth) max_depth = depth;
@@ -224,7 +232,7 @@ struct BvhBuilder {
         const size_t n = hi - lo;
         const bool is_point = cb.lo[0] == cb.hi[0] && cb.lo[1] == cb.hi[1] && cb.lo[2] == cb.hi[2];
         if (n == 1 || is_point) {
-            node.is_leaf = 1; node.idx = (uint32_t)leaf_order.size(); node.n_prims = (uint16_t)n;
+            node.is_leaf = 1; node.idx = (uint32_t)(leaf_base + leaf_order.size()); node.n_prims = (uint16_t)n;
             for (size_t i = lo; i < hi; i++) leaf_order.push_back(order[i]);
             nodes.push_back(node);
             return;
@@ -245,6 +253,94 @@ struct BvhBuilder {
         build(lo, lo + m, depth + 1);
         nodes[my].idx = (uint32_t)nodes.size();                                    /* second_child_idx = my + first_subtree_len + 1 */
         build(lo + m, hi, depth + 1);
+    }
+};
+
+/* Parallel driver for BvhBuilder: the top of the tree is split sequentially (same partitions as the serial build); every range
+ * of at most `grain` primitives becomes a task that builds its subtree into a private BvhBuilder-style buffer; the buffers are then
+ * stitched in DFS order with index fix-ups.  The result is identical to the serial build, node for node. */
+struct ParallelBvh {
+    BvhBuilder& B; size_t grain;
+    struct Task { size_t lo, hi; uint32_t depth; std::vector<ftn_bvh_node> nodes; std::vector<uint32_t> leaf_order; uint32_t max_depth = 0; };
+    struct Top { ftn_bvh_node node; int child[2]; bool is_task[2]; };
+    std::vector<Task> tasks; std::vector<Top> tops;
+    ParallelBvh(BvhBuilder& b, size_t g) : B(b), grain(g) {}
+    /* returns (index, is_task) */
+    std::pair<int, bool> split(size_t lo, size_t hi, uint32_t depth) {
+        if (hi - lo <= grain) { Task t; t.lo = lo; t.hi = hi; t.depth = depth; tasks.push_back(std::move(t)); return {(int)tasks.size() - 1, true}; }
+        Aabb nb = aabb_empty(), cb = aabb_empty();
+        for (size_t i = lo; i < hi; i++) {
+            const uint32_t p = B.order[i]; const Aabb& b = B.bounds[p];
+            for (int k = 0; k < 3; k++) { nb.lo[k] = fmin_(nb.lo[k], b.lo[k]); nb.hi[k] = fmax_(nb.hi[k], b.hi[k]); cb.lo[k] = fmin_(cb.lo[k], B.centroid[3 * p + k]); cb.hi[k] = fmax_(cb.hi[k], B.centroid[3 * p + k]); }
+        }
+        const bool is_point = cb.lo[0] == cb.hi[0] && cb.lo[1] == cb.hi[1] && cb.lo[2] == cb.hi[2];
+        if (is_point) { Task t; t.lo = lo; t.hi = hi; t.depth = depth; tasks.push_back(std::move(t)); return {(int)tasks.size() - 1, true}; }   /* becomes one leaf */
+        Top tp; memset(&tp.node, 0, sizeof(tp.node));
+        for (int k = 0; k < 3; k++) { tp.node.bmin[k] = nb.lo[k]; tp.node.bmax[k] = nb.hi[k]; }
+        const float dx = cb.hi[0] - cb.lo[0], dy = cb.hi[1] - cb.lo[1], dz = cb.hi[2] - cb.lo[2];
+        const int ax = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
+        const float mid = (cb.lo[ax] + cb.hi[ax]) / 2.0f;
+        uint32_t* first = B.order.data() + lo; uint32_t* last = B.order.data() + hi;
+        uint32_t* sp = std::partition(first, last, [&](uint32_t p) { return B.centroid[3 * p + ax] < mid; });
+        size_t m = (size_t)(sp - first), n = hi - lo;
+        if (m == 0 || m == n) { m = n / 2; std::nth_element(first, first + m, last, [&](uint32_t a, uint32_t b) { return B.centroid[3 * a + ax] < B.centroid[3 * b + ax]; }); }
+        tp.node.is_leaf = 0; tp.node.axis = (uint8_t)ax;
+        const int me = (int)tops.size();
+        tops.push_back(tp);
+        auto c0 = split(lo, lo + m, depth + 1);
+        auto c1 = split(lo + m, hi, depth + 1);
+        tops[me].child[0] = c0.first; tops[me].is_task[0] = c0.second; tops[me].child[1] = c1.first; tops[me].is_task[1] = c1.second;
+        return {me, false};
+    }
+    void run_tasks(int n_threads) {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                size_t k = next.fetch_add(1); if (k >= tasks.size()) break;
+                Task& t = tasks[k];
+                BvhBuilder sub(B.bounds, B.centroid, B.order, t.lo);      /* shares bounds / centroids / the order array (disjoint ranges) */
+                sub.build(t.lo, t.hi, t.depth);
+                t.nodes.swap(sub.nodes); t.leaf_order.swap(sub.leaf_order); t.max_depth = sub.max_depth;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_threads; i++) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+    }
+    /* stitch: offsets by one sequential DFS over the (small) top tree, then the copies in parallel */
+    std::vector<size_t> task_off;
+    size_t assign(int idx, bool is_task, size_t off) {
+        if (is_task) { task_off[idx] = off; return off + tasks[idx].nodes.size(); }
+        ftn_bvh_node& n = tops[idx].node;
+        const size_t my = off;
+        off = assign(tops[idx].child[0], tops[idx].is_task[0], off + 1);
+        n.idx = (uint32_t)off;                                   /* second_child_idx */
+        off = assign(tops[idx].child[1], tops[idx].is_task[1], off);
+        top_off[idx] = my;
+        return off;
+    }
+    std::vector<size_t> top_off;
+    void stitch(std::pair<int, bool> root, int n_threads) {
+        task_off.assign(tasks.size(), 0); top_off.assign(tops.size(), 0);
+        const size_t total = assign(root.first, root.second, 0);
+        B.nodes.resize(total); B.leaf_order.resize(B.order.size());
+        for (size_t i = 0; i < tops.size(); i++) B.nodes[top_off[i]] = tops[i].node;
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                size_t k = next.fetch_add(1); if (k >= tasks.size()) break;
+                Task& t = tasks[k];
+                const uint32_t base = (uint32_t)task_off[k];
+                ftn_bvh_node* dst = B.nodes.data() + task_off[k];
+                for (size_t i = 0; i < t.nodes.size(); i++) { ftn_bvh_node n = t.nodes[i]; if (!n.is_leaf) n.idx += base; dst[i] = n; }
+                memcpy(B.leaf_order.data() + t.lo, t.leaf_order.data(), t.leaf_order.size() * sizeof(uint32_t));
+                std::vector<ftn_bvh_node>().swap(t.nodes); std::vector<uint32_t>().swap(t.leaf_order);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_threads; i++) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+        for (const Task& t : tasks) if (t.max_depth > B.max_depth) B.max_depth = t.max_depth;
     }
 };
 
@@ -297,7 +393,25 @@ static int build_host_scene(const ftn_scene_desc* d, HostScene* hs) {
     hs->world = aabb_empty();
     if (d->n_prims) {
         BvhBuilder b(pb);
-        b.build(0, d->n_prims, 0);
+        int n_threads = (int)std::thread::hardware_concurrency();
+        if (const char* e = getenv("FTN_BVH_THREADS")) n_threads = atoi(e);
+        if (n_threads > 32) n_threads = 32;
+        if (n_threads > 1 && d->n_prims >= (1u << 16)) {
+            const bool dbg = getenv("FTN_BVH_DEBUG") != nullptr;
+            auto t0 = std::chrono::steady_clock::now();
+            ParallelBvh pb2(b, std::max<size_t>(4096, d->n_prims / (size_t)(n_threads * 8)));
+            auto root = pb2.split(0, d->n_prims, 0);
+            auto t1 = std::chrono::steady_clock::now();
+            pb2.run_tasks(n_threads);
+            auto t2 = std::chrono::steady_clock::now();
+            pb2.stitch(root, n_threads);
+            auto t3 = std::chrono::steady_clock::now();
+            if (dbg) fprintf(stderr, "[ftn bvh] %d threads, %zu tasks: top split %.2fs, subtrees %.2fs, stitch %.2fs\n", n_threads, pb2.tasks.size(),
+                             std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), std::chrono::duration<double>(t3 - t2).count());
+            /* depth of the top part */
+            std::function<void(int, bool, uint32_t)> walk = [&](int i, bool t, uint32_t dep) { if (t) return; if (dep > b.max_depth) b.max_depth = dep; walk(pb2.tops[i].child[0], pb2.tops[i].is_task[0], dep + 1); walk(pb2.tops[i].child[1], pb2.tops[i].is_task[1], dep + 1); };
+            walk(root.first, root.second, 0);
+        } else b.build(0, d->n_prims, 0);
         hs->nodes.swap(b.nodes); hs->order.swap(b.leaf_order); hs->max_depth = b.max_depth;
         for (int k = 0; k < 3; k++) { hs->world.lo[k] = hs->nodes[0].bmin[k]; hs->world.hi[k] = hs->nodes[0].bmax[k]; }
     }
