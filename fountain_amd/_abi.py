@@ -138,4 +138,7 @@ DECLARED_FUNCTIONS = [
     "ftn_scene_destroy", "ftn_bvh_build", "ftn_scene_info", "ftn_scene_get_nodes", "ftn_scene_get_lights",
     "ftn_intersect", "ftn_intersect_test", "ftn_intersect_full", "ftn_render", "ftn_render_device",
     "ftn_last_error", "ftn_device_count", "ftn_version", "ftn_test_math",
+    "ftn_pbrt_load", "ftn_pbrt_destroy", "ftn_pbrt_scene", "ftn_pbrt_camera", "ftn_pbrt_film",
+    "ftn_pbrt_samples_per_pixel", "ftn_pbrt_film_name", "ftn_pbrt_last_error", "ftn_ply_load",
+    "ftn_film_resolve_device", "ftn_exr_write", "ftn_exr_read", "ftn_imageio_last_error",
 ]

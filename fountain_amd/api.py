@@ -276,7 +276,7 @@ class SceneBuilder:
         self._tf[-1] = self._tf[-1] * t
 
     def reverse_orientation(self):
-        self._state[-1]["rev"] = not self._state[-1]["rev"]
+        self._state[-1]["rev"] = True      # sets, does not toggle (pbrt.rs:203-205)
 
     def _add_material(self, type_, a=(0, 0, 0), b=(0, 0, 0), s0=0.0, s1=0.0, s2=0.0, remap=True):
         m = A.ftn_material()
@@ -472,6 +472,83 @@ class SceneBuilder:
         return Scene(self.be, d, keep, device)
 
 
+class PbrtScene:
+    """A parsed .pbrt file (loaders/pbrt.rs PbrtHeader + PbrtSceneBuilder evaluated by the library's C++ reader):
+    .camera / .film / .sampler mirror make_camera / make_film / make_sampler; create_scene() -> BVH::build + upload."""
+
+    def __init__(self, path, backend=None):
+        self.be = be = backend or default_backend()
+        if be.is_oracle:
+            raise ValueError("scene files are read by the product library only")
+        self.handle = C.c_void_p()
+        load = be.lib.ftn_pbrt_load
+        load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        rc = load(os.fsencode(path), C.byref(self.handle))
+        if rc != 0:
+            err = be.lib.ftn_pbrt_last_error
+            err.restype = C.c_char_p
+            raise FountainError(rc, err().decode())
+        for name, typ in (("scene", A.ftn_scene_desc), ("camera", A.ftn_camera_desc), ("film", A.ftn_film_desc)):
+            f = getattr(be.lib, "ftn_pbrt_" + name)
+            f.restype = C.POINTER(typ)
+            f.argtypes = [C.c_void_p]
+        be.lib.ftn_pbrt_samples_per_pixel.argtypes = [C.c_void_p]
+        be.lib.ftn_pbrt_film_name.argtypes = [C.c_void_p]
+        be.lib.ftn_pbrt_film_name.restype = C.c_char_p
+        self.desc = be.lib.ftn_pbrt_scene(self.handle).contents
+        self.samples_per_pixel = be.lib.ftn_pbrt_samples_per_pixel(self.handle)
+        self.film_name = be.lib.ftn_pbrt_film_name(self.handle).decode()
+        self.camera = PerspectiveCamera.__new__(PerspectiveCamera)
+        self.camera.be = be
+        self.camera.desc = be.lib.ftn_pbrt_camera(self.handle).contents
+        self._film_desc = be.lib.ftn_pbrt_film(self.handle).contents
+
+    def film(self):
+        """A fresh Film (make_film, pbrt.rs:487-505)."""
+        return Film.from_desc(self.be, self._film_desc)
+
+    def sampler(self, override_samples=None, **kw):
+        """make_sampler (pbrt.rs:468-485): RandomSampler::new_with_seed(spp, 0)."""
+        return RandomSampler.new_with_seed(override_samples or self.samples_per_pixel, 0, **kw)
+
+    def create_scene(self, device=0):
+        return Scene(self.be, self.desc, [self], device)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                d = self.be.lib.ftn_pbrt_destroy
+                d.argtypes = [C.c_void_p]
+                d.restype = None
+                d(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def load_ply(path, backend=None):
+    """make_triangle_mesh_from_ply's reader (constructors.rs:94-190) -> (P [nv,3], N or None, UV or None, idx [nt,3])."""
+    be = backend or default_backend()
+    f = be.lib.ftn_ply_load
+    f.argtypes = [C.c_char_p] + [C.c_void_p] * 8
+    nv, nt, hn, huv = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_int()
+
+    def call(*arrs):
+        rc = f(os.fsencode(path), C.cast(C.byref(nv), C.c_void_p), C.cast(C.byref(nt), C.c_void_p), *arrs,
+               C.cast(C.byref(hn), C.c_void_p), C.cast(C.byref(huv), C.c_void_p))
+        if rc != 0:
+            err = be.lib.ftn_pbrt_last_error
+            err.restype = C.c_char_p
+            raise FountainError(rc, err().decode())
+    call(None, None, None, None)
+    P = np.empty((nv.value, 3), np.float32)
+    N = np.empty((nv.value, 3), np.float32)
+    UV = np.empty((nv.value, 2), np.float32)
+    idx = np.empty((nt.value, 3), np.uint32)
+    call(*[a.ctypes.data_as(C.c_void_p) for a in (P, N, UV, idx)])
+    return P, (N if hn.value else None), (UV if huv.value else None), idx
+
+
 class Scene:
     """Scene (src/scene/mod.rs:14-18) as an opaque device-resident handle."""
 
@@ -587,7 +664,8 @@ class PerspectiveCamera:
     @classmethod
     def look_at(cls, be, eye, look, up, full_resolution, **kw):
         """`LookAt` + `Camera "perspective"`: camera_tf = look_at(..), cam2world = inverse (pbrt.rs:431-433, :586-590)."""
-        return cls(be, Transform.look_at(be, eye, look, up).inverse(), full_resolution, **kw)
+        # the header CTM is identity * look_at (eval_transform_stmt multiplies even by the identity, which turns -0 into +0)
+        return cls(be, (Transform.identity(be) * Transform.look_at(be, eye, look, up)).inverse(), full_resolution, **kw)
 
 
 class Film:
@@ -599,6 +677,17 @@ class Film:
         c = self.desc.crop
         self.width, self.height = c[2] - c[0], c[3] - c[1]
         self.pixels = np.zeros((self.height, self.width, 4), np.float32)   # Pixel{xyz, filter_weight_sum}
+
+    @classmethod
+    def from_desc(cls, be, desc):
+        f = cls.__new__(cls)
+        f.be = be
+        f.desc = A.ftn_film_desc()
+        C.memmove(C.byref(f.desc), C.byref(desc), C.sizeof(desc))
+        c = f.desc.crop
+        f.width, f.height = c[2] - c[0], c[3] - c[1]
+        f.pixels = np.zeros((f.height, f.width, 4), np.float32)
+        return f
 
     def sample_bounds(self):
         out = (C.c_int32 * 4)()
@@ -615,6 +704,47 @@ class Film:
         rgb = np.empty((self.height, self.width, 3), np.float32)
         self.be.call("film_resolve", self.pixels.ctypes.data_as(C.c_void_p), C.c_size_t(self.width * self.height), _fptr(rgb))
         return rgb, (self.width, self.height)
+
+
+def _io_error(be, rc):
+    err = be.lib.ftn_imageio_last_error
+    err.restype = C.c_char_p
+    return FountainError(rc, err().decode())
+
+
+def write_exr(path, rgb, backend=None):
+    """write_exr (imageio/exr.rs:47-87): rgb [h, w, 3] float32 -> scanline OpenEXR with FLOAT R, G, B channels."""
+    be = backend or default_backend()
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[0], rgb.shape[1]
+    f = be.lib.ftn_exr_write
+    f.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    rc = f(os.fsencode(path), rgb.ctypes.data_as(C.c_void_p), w, h)
+    if rc != 0:
+        raise _io_error(be, rc)
+
+
+def read_exr(path, backend=None):
+    """read_exr (imageio/exr.rs:11-45) -> rgb [h, w, 3] float32."""
+    be = backend or default_backend()
+    f = be.lib.ftn_exr_read
+    f.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = f(os.fsencode(path), C.cast(C.byref(w), C.c_void_p), C.cast(C.byref(h), C.c_void_p), None)
+    if rc != 0:
+        raise _io_error(be, rc)
+    rgb = np.empty((h.value, w.value, 3), np.float32)
+    rc = f(os.fsencode(path), C.cast(C.byref(w), C.c_void_p), C.cast(C.byref(h), C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise _io_error(be, rc)
+    return rgb
+
+
+def film_resolve_device(be, device_pixels_ptr, n_pixels, device_rgb_ptr, stream_ptr=0):
+    """Film::into_spectrum_buffer (film.rs:195-210) with both buffers in HBM (device pointers)."""
+    f = be.lib.ftn_film_resolve_device
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    be.check(f(C.c_void_p(device_pixels_ptr), n_pixels, C.c_void_p(device_rgb_ptr), C.c_void_p(stream_ptr)))
 
 
 class RandomSampler:

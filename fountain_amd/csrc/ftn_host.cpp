@@ -459,6 +459,7 @@ struct ftn_scene {
     /* render work buffers (grow-only, reused across calls) */
     DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
     WavefrontState* wf = nullptr;
+    std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
         nodes.release(); geom.release(); fat.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
@@ -734,10 +735,18 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
         return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED + FTN_INTEGRATOR_PATH");
     const bool count = opt && opt->count_traffic;
 
-    std::vector<DTile> all, sel; list_tiles(film, &all);
     const uint32_t stride = tr && tr->stride ? tr->stride : 1, first = tr ? tr->first : 0, cnt = tr ? tr->count : 0;
-    for (size_t i = first, k = 0; i < all.size() && (cnt == 0 || k < cnt); i += stride, k++) sel.push_back(all[i]);
-    { uint32_t off = 0; for (DTile& t : sel) { t.valid_off = off; t._pad = 0; off += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0)); } }
+    /* the tile list only depends on the film and the tile range: keep it (and its device copy) between calls */
+    int32_t key[10] = {film->crop[0], film->crop[1], film->crop[2], film->crop[3], (int32_t)ftn_det::f2u(film->filter_radius[0]), (int32_t)ftn_det::f2u(film->filter_radius[1]),
+                       (int32_t)first, (int32_t)stride, (int32_t)cnt, 1};
+    const bool tiles_cached = memcmp(key, s->tile_key, sizeof(key)) == 0;
+    if (!tiles_cached) {
+        std::vector<DTile> all; list_tiles(film, &all);
+        s->sel.clear();
+        for (size_t i = first, k = 0; i < all.size() && (cnt == 0 || k < cnt); i += stride, k++) s->sel.push_back(all[i]);
+        uint32_t off = 0; for (DTile& t : s->sel) { t.valid_off = off; t._pad = 0; off += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0)); }
+    }
+    std::vector<DTile>& sel = s->sel;
 
     RenderParams P; memset(&P, 0, sizeof(P));
     P.S = s->d;
@@ -762,7 +771,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     HIP_TRY(hipMemsetAsync(s->accB.p, 0, npix * sizeof(float4), stream));
     HIP_TRY(hipMemsetAsync(s->accC.p, 0, npix * sizeof(float4), stream));
     HIP_TRY(hipMemsetAsync(s->stats.p, 0, sizeof(DevStats), stream));
-    if (!sel.empty()) HIP_TRY(hipMemcpyAsync(s->tiles.p, sel.data(), sel.size() * sizeof(DTile), hipMemcpyHostToDevice, stream));
+    if (!sel.empty() && !tiles_cached) { HIP_TRY(hipMemcpyAsync(s->tiles.p, sel.data(), sel.size() * sizeof(DTile), hipMemcpyHostToDevice, stream)); memcpy(s->tile_key, key, sizeof(key)); }
     P.tiles = s->tiles.p; P.n_tiles = (uint32_t)sel.size();
     P.accA = s->accA.p; P.accB = s->accB.p; P.accC = s->accC.p; P.stats = s->stats.p;
 
@@ -792,6 +801,15 @@ int ftn_test_math(int which, const float* x, const float* y, size_t n, float* ou
     hipError_t e = hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost);
     dx.release(); dy.release(); dout.release();
     if (e != hipSuccess) return fail(FTN_ERR_NO_DEVICE, hipGetErrorString(e));
+    return FTN_OK;
+}
+
+int ftn_film_resolve_device(const void* device_pixels, size_t n, void* device_rgb_out, void* stream) {   /* film.rs:195-210 in HBM */
+    if (!device_pixels || !device_rgb_out) return fail(FTN_ERR_INVALID_ARGUMENT, "null argument");
+    if (ftn_device_count() <= 0) return fail(FTN_ERR_NO_DEVICE, "no HIP device");
+    launch_spectrum_buffer((const ftn_pixel*)device_pixels, n, (float*)device_rgb_out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FTN_ERR_INTERNAL, hipGetErrorString(e));
     return FTN_OK;
 }
 

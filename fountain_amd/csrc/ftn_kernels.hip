@@ -344,6 +344,24 @@ void launch_film_resolve(const RenderParams& p, ftn_pixel* device_pixels, hipStr
     hipLaunchKernelGGL(k_film_resolve, dim3(grid), dim3(256), 0, stream, p.accA, p.accB, p.accC, device_pixels, n);
 }
 
+/* ------------------------------------------------------------------ Film::into_spectrum_buffer: film.rs:195-210.  16 B in, 12 B out per pixel */
+__global__ void __launch_bounds__(256) k_spectrum_buffer(const float4* __restrict__ px, float* __restrict__ rgb_out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float4 p = px[i];
+        const float xyz[3] = {p.x, p.y, p.z};
+        float rgb[3]; xyz_to_rgb(xyz, rgb);
+        if (p.w != 0.0f) { const float inv = 1.0f / p.w; rgb[0] = fmax_(0.0f, rgb[0] * inv); rgb[1] = fmax_(0.0f, rgb[1] * inv); rgb[2] = fmax_(0.0f, rgb[2] * inv); }
+        rgb_out[3 * i] = rgb[0]; rgb_out[3 * i + 1] = rgb[1]; rgb_out[3 * i + 2] = rgb[2];
+    }
+}
+void launch_spectrum_buffer(const ftn_pixel* device_pixels, size_t n, float* device_rgb, hipStream_t stream) {
+    if (n == 0) return;
+    unsigned grid = (unsigned)((n + 255) / 256); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_spectrum_buffer, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(device_pixels), device_rgb, n);
+}
+
 /* ------------------------------------------------------------------ batch Scene::intersect / intersect_test / full interaction */
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(256) k_trace_batch(DScene S, const float* __restrict__ rays, size_t n, float* t_hit, int* prim, float* bary,

@@ -337,6 +337,38 @@ int ftn_render_device(const ftn_scene* scene, const ftn_camera_desc* camera, con
                       const ftn_tile_range* tiles, const ftn_render_options* options,
                       void* device_pixels, void* stream, ftn_stats* stats);
 
+/* ------------------------------------------------------------------ scene ingestion (host only)
+ * The subset of the PBRT v3 format the reference evaluates: PbrtHeader::exec_stmt + make_camera / make_sampler / make_film
+ * (src/loaders/pbrt.rs:426-532) and PbrtSceneBuilder::exec_stmt (pbrt.rs:178-330) with the defaults of
+ * src/loaders/constructors.rs:38-359.  Include files and `Shape "plymesh"` resolve relative to the scene file.  Statements the
+ * reference leaves unimplemented!() and non-constant textures return FTN_ERR_UNSUPPORTED; Integrator / PixelFilter / Accelerator
+ * are ignored as in the reference (pbrt.rs:528-530).  The descriptors stay owned by the handle.                           */
+typedef struct ftn_pbrt ftn_pbrt;
+int ftn_pbrt_load(const char* path, ftn_pbrt** out);
+void ftn_pbrt_destroy(ftn_pbrt* p);
+const ftn_scene_desc* ftn_pbrt_scene(const ftn_pbrt* p);      /* pass to ftn_scene_create                      */
+const ftn_camera_desc* ftn_pbrt_camera(const ftn_pbrt* p);    /* PbrtHeader::make_camera                       */
+const ftn_film_desc* ftn_pbrt_film(const ftn_pbrt* p);        /* PbrtHeader::make_film                         */
+int ftn_pbrt_samples_per_pixel(const ftn_pbrt* p);            /* Sampler "pixelsamples", default 16 (pbrt.rs:470-472) */
+const char* ftn_pbrt_film_name(const ftn_pbrt* p);            /* Film "filename"                               */
+const char* ftn_pbrt_last_error(void);                        /* message of the last failed ftn_pbrt_load / ftn_ply_load on this thread */
+/* make_triangle_mesh_from_ply's reader (constructors.rs:94-190): ASCII or binary_little_endian, float x y z [nx ny nz] [u v],
+ * triangle faces only.  Call once with NULL arrays for the counts, then with arrays of 3*nv / 3*nv / 2*nv floats and 3*nt indices. */
+int ftn_ply_load(const char* path, uint32_t* n_vertices, uint32_t* n_triangles, float* P, float* N, float* UV,
+                 uint32_t* indices, int* has_normals, int* has_uvs);
+
+/* ------------------------------------------------------------------ output stage
+ * Film::into_spectrum_buffer (src/film.rs:195-210) on the device: device_pixels -> device_rgb (3 floats per pixel), both DEVICE
+ * pointers, on `stream`.  Bit-identical to ftn_film_resolve on the host.                                                  */
+int ftn_film_resolve_device(const void* device_pixels, size_t n_pixels, void* device_rgb_out, void* stream);
+/* write_exr / read_exr (src/imageio/exr.rs:11-87): scanline OpenEXR, FLOAT channels R G B, layer "image"; rgb is row-major,
+ * 3 floats per pixel.  The writer emits NO_COMPRESSION blocks (the reference's `exr` crate writes RLE: same samples, same layer);
+ * the reader accepts NO_COMPRESSION and RLE scanline files with FLOAT or HALF channels.  ftn_exr_read with rgb_out == NULL only
+ * reports the size.                                                                                                        */
+int ftn_exr_write(const char* path, const float* rgb, uint32_t width, uint32_t height);
+int ftn_exr_read(const char* path, uint32_t* width, uint32_t* height, float* rgb_out);
+const char* ftn_imageio_last_error(void);
+
 /* ------------------------------------------------------------------ test hook
  * Evaluates the deterministic math of the kernels ON THE DEVICE for arrays of HOST floats (parity tests compare the bits
  * with a CPU evaluation): which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x,y), 6 ln, 7 log2, 8 sqrt, 9 x/y,

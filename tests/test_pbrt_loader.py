@@ -1,0 +1,249 @@
+"""Scene ingestion: the library's C++ PBRT-subset reader and PLY reader against the call-by-call SceneBuilder
+(the path every other parity test uses) -- descriptors must be byte-identical.  Host only: no GPU needed.
+tests/golden/furnace_empty.pbrt is the reference's own test scene (testscenes/furnace_empty.pbrt, data, used by tests/furnace.rs)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from fountain_amd import FountainError, PbrtScene, SceneBuilder, Transform, PerspectiveCamera, Film, load_ply, load_ply_ascii, scenes
+from fountain_amd import _abi as A
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    nbytes = n * np.dtype(dtype).itemsize
+    return np.frombuffer(C.string_at(C.cast(ptr, C.c_void_p), nbytes), dtype=dtype).copy()
+
+
+def desc_arrays(d):
+    out = {
+        "prims": _arr(d.prims, d.n_prims * 4, np.int32),
+        "tri_indices": _arr(d.tri_indices, d.n_triangles * 3, np.uint32),
+        "tri_mesh": _arr(d.tri_mesh, d.n_triangles, np.uint32),
+        "P": _arr(d.P, d.n_vertices * 3, np.uint32),
+        "N": _arr(d.N, d.n_vertices * 3, np.uint32) if d.N else None,
+        "UV": _arr(d.UV, d.n_vertices * 2, np.uint32) if d.UV else None,
+        "meshes": _arr(d.meshes, d.n_meshes * 4, np.uint32),
+        "spheres": _arr(d.spheres, d.n_spheres * 72, np.uint32),
+        "materials": _arr(d.materials, d.n_materials * 11, np.uint32).reshape(-1, 11) if d.n_materials else np.zeros((0, 11), np.uint32),
+        "area_emit": _arr(d.area_emit, d.n_area_emit * 3, np.uint32),
+        "lights": _arr(d.lights, d.n_lights * 40, np.uint32),
+    }
+    # material _pad is not meaningful: compare the 11 leading words only (done by the reshape above: 48 B = 12 words)
+    out["materials"] = _arr(d.materials, d.n_materials * 12, np.uint32).reshape(-1, 12)[:, :11]
+    envs = []
+    for i in range(d.n_envmaps):
+        e = d.envmaps[i]
+        envs.append((e.width, e.height, _arr(e.texels, e.width * e.height * 3, np.uint32)))
+    out["envmaps"] = envs
+    return out
+
+
+def assert_same_desc(a, b):
+    da, db = desc_arrays(a), desc_arrays(b)
+    for k in da:
+        if k == "envmaps":
+            assert len(da[k]) == len(db[k])
+            for x, y in zip(da[k], db[k]):
+                assert x[0] == y[0] and x[1] == y[1] and np.array_equal(x[2], y[2])
+        elif da[k] is None or db[k] is None:
+            assert da[k] is None and db[k] is None, k
+        else:
+            assert da[k].shape == db[k].shape, k
+            assert np.array_equal(da[k], db[k]), k
+
+
+def same_struct(a, b):
+    return C.string_at(C.byref(a), C.sizeof(a)) == C.string_at(C.byref(b), C.sizeof(b))
+
+
+def test_reference_furnace_scene_file(ftn):
+    """testscenes/furnace_empty.pbrt == scenes.furnace(): sphere light with ReverseOrientation, LookAt camera, 16x16 film, 128 spp."""
+    ps = PbrtScene(os.path.join(GOLD, "furnace_empty.pbrt"), ftn)
+    b, cam, res = scenes.furnace(ftn, 16)
+    b.attribute_begin(); b.material("matte", Kd=(1, 1, 1)); b.attribute_end()      # the file's second, shapeless block
+    d, keep = b.build_desc()
+    assert_same_desc(ps.desc, d)
+    assert same_struct(ps.camera.desc, cam.desc)
+    assert same_struct(ps.film().desc, Film(ftn, res).desc)
+    assert ps.samples_per_pixel == 128 and ps.film_name == "furnace.exr"
+
+
+def test_cornell_scene_file(ftn):
+    ps = PbrtScene(os.path.join(GOLD, "cornell.pbrt"), ftn)
+    b, cam, res = scenes.cornell(ftn, 64)
+    d, keep = b.build_desc()
+    assert_same_desc(ps.desc, d)
+    assert same_struct(ps.camera.desc, cam.desc)
+    assert same_struct(ps.film().desc, Film(ftn, res).desc)
+    assert ps.samples_per_pixel == 8
+
+
+def _write_ply(path, P, N, UV, F, binary):
+    props = ["x", "y", "z"] + (["nx", "ny", "nz"] if N is not None else []) + (["u", "v"] if UV is not None else [])
+    cols = [P] + ([N] if N is not None else []) + ([UV] if UV is not None else [])
+    V = np.concatenate(cols, axis=1).astype("<f4")
+    hdr = "ply\nformat %s 1.0\ncomment test\nelement vertex %d\n" % ("binary_little_endian" if binary else "ascii", len(P))
+    hdr += "".join("property float %s\n" % p for p in props)
+    hdr += "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % len(F)
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if binary:
+            f.write(V.tobytes())
+            for tri in F:
+                f.write(struct.pack("<B3i", 3, *[int(x) for x in tri]))
+        else:
+            for row in V:
+                f.write((" ".join(repr(float(x)) for x in row) + "\n").encode())
+            for tri in F:
+                f.write(("3 %d %d %d\n" % tuple(int(x) for x in tri)).encode())
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_ply_reader_round_trips_the_reference_mesh(ftn, tmp_path, binary):
+    """data/rounded_cube.ply's content (tests/golden/rounded_cube.npz) written as ASCII and binary PLY reads back bit-exactly."""
+    P, N, F = scenes.rounded_cube_mesh()
+    UV = (P[:, :2] * np.float32(0.25) + np.float32(0.5)).astype(np.float32)
+    path = str(tmp_path / "m.ply")
+    _write_ply(path, P, N, UV, F, binary)
+    P2, N2, UV2, F2 = load_ply(path, ftn)
+    assert np.array_equal(P2.view(np.uint32), np.asarray(P, np.float32).view(np.uint32))
+    assert np.array_equal(N2.view(np.uint32), np.asarray(N, np.float32).view(np.uint32))
+    assert np.array_equal(UV2.view(np.uint32), UV.view(np.uint32))
+    assert np.array_equal(F2, np.asarray(F, np.uint32))
+    if not binary:   # the independent Python reader agrees
+        P3, N3, F3 = load_ply_ascii(path)
+        assert np.array_equal(P3, P2) and np.array_equal(N3, N2) and np.array_equal(F3, F2)
+
+
+def test_ply_reader_rejects_quads_and_missing_files(ftn, tmp_path):
+    p = tmp_path / "q.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    with pytest.raises(FountainError) as e:
+        load_ply(str(p), ftn)
+    assert e.value.code == A.FTN_ERR_UNSUPPORTED          # "Face with unsupported vertex count found" (constructors.rs:162)
+    with pytest.raises(FountainError):
+        load_ply(str(tmp_path / "missing.ply"), ftn)
+
+
+FEATURES = """
+# every statement kind of pbrt.rs:178-330 that is implemented in the reference
+Film "image" "integer xresolution" [ 96 ] "integer yresolution" [ 48 ] "float cropwindow" [ 0.25 0.75 0.1 0.9 ]
+Sampler "halton" "integer pixelsamples" 4
+Scale -1 1 1
+Rotate 12 0 0 1
+LookAt 1 -4 2  0 0 0.25  0 0 1
+Camera "perspective" "float fov" 35 "float lensradius" 0.05 "float focaldistance" 4.5 "float shutteropen" 0.25 "float shutterclose" 0.75
+Accelerator "bvh"
+WorldBegin
+MakeNamedMaterial "gold" "string type" "metal" "rgb eta" [0.143 0.375 1.442] "rgb k" [3.983 2.386 1.603] "float roughness" 0.05
+MakeNamedMaterial "brushed" "string type" "metal" "rgb eta" [0.2 0.9 1.1] "rgb k" [3.9 2.4 2.2] "float uroughness" 0.02 "float vroughness" 0.2 "bool remaproughness" "false"
+LightSource "point" "rgb I" [10 9 8] "rgb scale" [2 2 2] "point from" [0 0 3]
+LightSource "distant" "rgb L" [3 3 3] "point from" [1 1 1] "point to" [0 0 0]
+TransformBegin
+  Rotate -90 1 0 0
+  LightSource "infinite" "rgb L" [0.25 0.5 0.75]
+TransformEnd
+Include "inc.pbrt"
+AttributeBegin
+  NamedMaterial "gold"
+  ConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  0.5 0.25 0 1]
+  Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] "normal N" [0 0 1 0 0 1 0 0 1] "float uv" [0 0 1 0 0 1]
+  Transform [2 0 0 0  0 2 0 0  0 0 2 0  0 0 1 1]
+  NamedMaterial "brushed"
+  Shape "plymesh" "string filename" "cube.ply"
+AttributeEnd
+AttributeBegin
+  Material "glass" "float eta" 1.33 "rgb Kt" [0.9 0.9 1] "bool remaproughness" "false"
+  Scale 1 1 -1
+  Shape "sphere" "float radius" 0.5 "float zmin" -0.25 "float zmax" 0.4 "float phimax" 270
+  Material "matte" "rgb Kd" [0.1 0.2 0.3] "float sigma" 20
+  ReverseOrientation
+  Identity
+  Translate 0 0 -1
+  Shape "sphere"
+AttributeEnd
+Shape "sphere" "float radius" 0.1
+WorldEnd
+"""
+INC = """AttributeBegin
+  Material "mirror"
+  Translate 3 0 0
+  Shape "sphere" "float radius" 0.75
+AttributeEnd
+"""
+
+
+def test_every_supported_statement(ftn, tmp_path):
+    P, N, F = scenes.rounded_cube_mesh()
+    _write_ply(str(tmp_path / "cube.ply"), P, N, None, F, True)
+    (tmp_path / "inc.pbrt").write_text(INC)
+    (tmp_path / "s.pbrt").write_text(FEATURES)
+    ps = PbrtScene(str(tmp_path / "s.pbrt"), ftn)
+
+    b = SceneBuilder(ftn)
+    gold = b._add_material(A.FTN_MAT_METAL, a=(0.143, 0.375, 1.442), b=(3.983, 2.386, 1.603), s1=0.05, s2=0.05)
+    brushed = b._add_material(A.FTN_MAT_METAL, a=(0.2, 0.9, 1.1), b=(3.9, 2.4, 2.2), s1=0.02, s2=0.2, remap=False)
+    b.light_source("point", I=(10, 9, 8), scale=(2, 2, 2), from_=(0, 0, 3))
+    b.light_source("distant", L=(3, 3, 3), from_=(1, 1, 1), to=(0, 0, 0))
+    b.attribute_begin(); b.rotate(-90, (1, 0, 0)); b.light_source("infinite", L=(0.25, 0.5, 0.75)); b.attribute_end()
+    b.attribute_begin(); b.material("mirror"); b.translate((3, 0, 0)); b.shape("sphere", radius=0.75); b.attribute_end()
+    b.attribute_begin()
+    b._state[-1]["material"] = gold
+    b.concat_transform(Transform.from_flat(ftn, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.5, 0.25, 0, 1]))
+    b.shape("trianglemesh", indices=[0, 1, 2], P=[0, 0, 0, 1, 0, 0, 0, 1, 0], N=[0, 0, 1, 0, 0, 1, 0, 0, 1], uv=[0, 0, 1, 0, 0, 1])
+    b._tf[-1] = Transform.from_flat(ftn, [2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2, 0, 0, 0, 1, 1])
+    b._state[-1]["material"] = brushed
+    b.add_mesh(P, N, None, F, b._tf[-1], False, brushed, -1)
+    b.attribute_end()
+    b.attribute_begin()
+    b.material("glass", eta=1.33, Kt=(0.9, 0.9, 1.0), remaproughness=False)
+    b.scale(1, 1, -1)
+    b.shape("sphere", radius=0.5, zmin=-0.25, zmax=0.4, phimax=270.0)
+    b.material("matte", Kd=(0.1, 0.2, 0.3), sigma=20.0)
+    b.reverse_orientation(); b.identity(); b.translate((0, 0, -1)); b.shape("sphere")
+    b.attribute_end()
+    b.shape("sphere", radius=0.1)
+    d, keep = b.build_desc()
+    assert_same_desc(ps.desc, d)
+
+    w2c = Transform.scale(ftn, -1, 1, 1) * Transform.rotate(ftn, 12, (0, 0, 1)) * Transform.look_at(ftn, (1, -4, 2), (0, 0, 0.25), (0, 0, 1))
+    cam = PerspectiveCamera(ftn, w2c.inverse(), (96, 48), shutter=(0.25, 0.75), lens_radius=0.05, focal_dist=4.5, fov=35.0)
+    assert same_struct(ps.camera.desc, cam.desc)
+    assert same_struct(ps.film().desc, Film(ftn, (96, 48), crop_window=(0.25, 0.1, 0.75, 0.9)).desc)
+    assert ps.samples_per_pixel == 4 and ps.film_name == "render.exr"
+
+
+@pytest.mark.parametrize("body,code", [
+    ('ObjectBegin "a"', A.FTN_ERR_UNSUPPORTED),                                             # unimplemented!() pbrt.rs:196
+    ('Texture "t" "spectrum" "checkerboard"', A.FTN_ERR_UNSUPPORTED),                      # non-constant textures: 8(f).2
+    ('Material "matte" "texture Kd" "t"', A.FTN_ERR_UNSUPPORTED),
+    ('Material "velvet"', A.FTN_ERR_INVALID_ARGUMENT),                                      # UnknownName
+    ('NamedMaterial "nope"', A.FTN_ERR_INVALID_ARGUMENT),                                   # MaterialError
+    ('Shape "cone"', A.FTN_ERR_INVALID_ARGUMENT),
+    ('Material "metal" "float roughness" 0.1', A.FTN_ERR_INVALID_ARGUMENT),                 # eta / k are required (constructors.rs:215)
+    ('AttributeEnd', A.FTN_ERR_INVALID_ARGUMENT),
+    ('CoordinateSystem "x"', A.FTN_ERR_UNSUPPORTED),
+])
+def test_errors_follow_the_reference(ftn, tmp_path, body, code):
+    p = tmp_path / "e.pbrt"
+    p.write_text('Camera "perspective"\nWorldBegin\n%s\nWorldEnd\n' % body)
+    with pytest.raises(FountainError) as e:
+        PbrtScene(str(p), ftn)
+    assert e.value.code == code, e.value
+
+
+def test_plastic_reads_lowercase_ks(ftn, tmp_path):
+    """constructors.rs:232-238 looks up "ks": a file's "Ks" is ignored and the 0.25 default applies."""
+    p = tmp_path / "p.pbrt"
+    p.write_text('Camera "perspective"\nWorldBegin\nMaterial "plastic" "rgb Ks" [1 1 1]\nShape "sphere"\nWorldEnd\n')
+    ps = PbrtScene(str(p), ftn)
+    m = ps.desc.materials[ps.desc.prims[0].material]
+    assert m.type == A.FTN_MAT_PLASTIC and list(m.b) == [0.25, 0.25, 0.25]
