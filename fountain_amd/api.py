@@ -76,11 +76,37 @@ class Backend:
 _default_backend = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so under torch/lib with the same SONAME as /opt/rocm's.  Two HIP
+    runtimes in one process each try to own the device ("No HIP GPUs are available" from whichever initialises second), so
+    when torch is installed its copy is loaded first and libfountain_hip.so binds to it; device pointers and streams of torch
+    tensors are then valid in ftn_render_device.  FTN_HIP_RUNTIME=system skips this."""
+    if os.environ.get("FTN_HIP_RUNTIME", "torch") != "torch":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    lib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(lib):
+        try:
+            C.CDLL(lib, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def default_backend():
     """The HIP product library; raises loudly if it has not been built."""
     global _default_backend
     if _default_backend is None:
         here = os.path.dirname(os.path.abspath(__file__))
+        _share_hip_runtime_with_torch()
         _default_backend = Backend(os.path.join(here, os.environ.get("FTN_LIB", "libfountain_hip.so")), "ftn_", False)
     return _default_backend
 
