@@ -22,6 +22,7 @@
 #include "ftn_wavefront.h"
 #include <string>
 #include <cstdlib>
+#include <hipcub/hipcub.hpp>
 
 namespace ftn {
 
@@ -757,7 +758,27 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
 static thread_local std::string g_wf_err;
 const char* wavefront_error() { return g_wf_err.c_str(); }
 
+/* ------------------------------------------------------------------ experiment (FTN_WF_SORT): order a ray queue by origin cell and direction octant */
+__device__ inline uint32_t spread3(uint32_t v) {   /* 10 bits -> every third bit */
+    v &= 0x3ffu; v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u; return v;
+}
+template <bool ANY>
+__global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, uint32_t count, uint32_t* __restrict__ keys, uint32_t mode, uint32_t bits) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t rid = queue[i];
+    const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + W.n_paths : rid);
+    const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
+    const float ex = S.root_hi[0] - S.root_lo[0], ey = S.root_hi[1] - S.root_lo[1], ez = S.root_hi[2] - S.root_lo[2];
+    const float sc = (float)(1u << bits);
+    const float fx = fminf(fmaxf((a.x - S.root_lo[0]) / ex, 0.0f), 0.999f) * sc, fy = fminf(fmaxf((a.y - S.root_lo[1]) / ey, 0.0f), 0.999f) * sc, fz = fminf(fmaxf((a.z - S.root_lo[2]) / ez, 0.0f), 0.999f) * sc;
+    const uint32_t m = spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
+    const uint32_t oct = (b.x < 0.0f ? 1u : 0u) | (b.y < 0.0f ? 2u : 0u) | (b.z < 0.0f ? 4u : 0u);
+    keys[i] = mode == 1 ? ((oct << (3 * bits)) | m) : ((m << 3) | oct);
+}
+
 struct WavefrontState {
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     size_t cap_paths = 0;
     void* mem[32]; int n_mem = 0;
     WfBuffers W;
@@ -835,8 +856,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (n_slots == 0) return FTN_OK;
     const uint32_t total_samples = P.last_sample - P.first_sample;
     if (total_samples == 0) return FTN_OK;
-    /* samples per pass: about 8M paths in flight (enough to fill 256 CUs for every bounce, bounded HBM) */
-    uint32_t S = (uint32_t)std::max<size_t>(1, (size_t)(8u << 20) / n_slots);
+    /* samples per pass: about 16M paths in flight (fills 256 CUs for every bounce; ~6 GB of path state in HBM) */
+    uint32_t S = (uint32_t)std::max<size_t>(1, (size_t)(16u << 20) / n_slots);
     S = std::min(S, total_samples);
     int rc = wf_reserve(st, (size_t)S * n_slots); if (rc) return rc;
     WfBuffers W = st->W;
@@ -854,7 +875,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     auto flush_events = [&]() -> int {
         if (spans.empty()) return FTN_OK;
         WF_TRY(hipEventSynchronize(st->ev[spans.back().b]));
-        for (const Span& s : spans) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, st->ev[s.a], st->ev[s.b]); trace_ms += ms; }
+        for (const Span& s : spans) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, st->ev[s.a], st->ev[s.b]); trace_ms += ms; if (knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] closest-hit launch: %.3f ms\n", ms); }
         spans.clear(); ev_used = 0;
         return FTN_OK;
     };
@@ -884,6 +905,25 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
             hipLaunchKernelGGL(k_wf_shade, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
             in_q ^= 1;
+            if (const uint32_t sort_mode = knob("FTN_WF_SORT", 0)) {   /* experiment: reorder the two ray queues for the next traces */
+                const uint32_t bits = knob("FTN_WF_SORT_BITS", 7);
+                WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                WF_TRY(hipStreamSynchronize(stream));
+                const uint32_t n_cl = st->host_counters[CTR(2)], n_sh = st->host_counters[CTR(3)];
+                const size_t n = st->cap_paths;
+                uint32_t* out_cl = W.q_sorted, *out_sh = W.q_sorted + 2 * n, *k_in = W.q_sorted + 3 * n, *k_out = W.q_sorted + 5 * n;
+                for (int pass = 0; pass < 2; pass++) {
+                    const uint32_t cnt = pass ? n_sh : n_cl; if (cnt == 0) continue;
+                    uint32_t* q = pass ? W.q_shadow : W.q_closest; uint32_t* out = pass ? out_sh : out_cl;
+                    if (pass) hipLaunchKernelGGL(k_wf_ray_keys<true>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, q, cnt, k_in, sort_mode, bits);
+                    else hipLaunchKernelGGL(k_wf_ray_keys<false>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, q, cnt, k_in, sort_mode, bits);
+                    size_t need = 0;
+                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, q, out, (int)cnt, 0, (int)(3 * bits + 3), stream));
+                    if (need > st->sort_tmp_bytes) { if (st->sort_tmp) (void)hipFree(st->sort_tmp); WF_TRY(hipMalloc(&st->sort_tmp, need)); st->sort_tmp_bytes = need; }
+                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, k_in, k_out, q, out, (int)cnt, 0, (int)(3 * bits + 3), stream));
+                    WF_TRY(hipMemcpyAsync(q, out, (size_t)cnt * 4, hipMemcpyDeviceToDevice, stream));
+                }
+            }
             if (it >= P.max_depth) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
                 WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 WF_TRY(hipStreamSynchronize(stream));

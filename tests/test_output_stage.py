@@ -163,3 +163,35 @@ def test_device_film_and_spectrum_buffer_match_host(gpu, tmp_path):
     img = read_exr(out, gpu)
     assert img.shape == (16, 16, 3)
     assert np.all(np.abs(img - 2.0) <= 1e-3)                     # tests/furnace.rs path_no_rr: L -> 1/(1-0.5) = 2, eps 0.001
+
+
+@pytest.mark.gpu
+def test_rccl_film_merge_single_rank(gpu):
+    """The multi-GPU merge (fountain_amd.distributed.merge_film) over the real RCCL backend, with the one rank this box has:
+    render a tile shard into a device film, reduce, compare with the host render.  (N > 1 semantics: tests/test_multigpu_gloo.py.)"""
+    import torch
+    import torch.distributed as dist
+    from fountain_amd import Film, PathIntegrator, RandomSampler, SamplerIntegrator, scenes
+    from fountain_amd.distributed import merge_film, tile_shard
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        b, cam, res = scenes.cornell(gpu, 64)
+        scene = b.create_scene()
+        integ = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+        dev = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device="cuda:0")
+        integ.render_device(scene, Film(gpu, res), RandomSampler(2, indexed=True), dev.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                            tiles=tile_shard(0, 1))
+        # with world_size 1 merge_film is the identity; force the collective itself as well
+        merged = merge_film(dev)
+        dist.reduce(dev, dst=0, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        torch.cuda.synchronize()
+        host = Film(gpu, res)
+        integ.render_parallel(scene, host, RandomSampler(2, indexed=True))
+        assert np.array_equal(merged.cpu().numpy().view(np.uint32), host.pixels.view(np.uint32))
+    finally:
+        dist.destroy_process_group()
