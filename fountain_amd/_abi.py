@@ -23,7 +23,7 @@ FTN_SHAPE_TRIANGLE, FTN_SHAPE_SPHERE = 0, 1
 FTN_MAT_MATTE, FTN_MAT_METAL, FTN_MAT_MIRROR, FTN_MAT_PLASTIC, FTN_MAT_GLASS = range(5)
 FTN_LIGHT_POINT, FTN_LIGHT_DISTANT, FTN_LIGHT_INFINITE = range(3)
 FTN_SAMPLER_TILE_SERIAL, FTN_SAMPLER_INDEXED = 0, 1
-FTN_INTEGRATOR_PATH, FTN_INTEGRATOR_DIRECT_LIGHTING = 0, 1
+FTN_INTEGRATOR_PATH, FTN_INTEGRATOR_DIRECT_LIGHTING, FTN_INTEGRATOR_WHITTED = 0, 1, 2
 FTN_PIPELINE_AUTO, FTN_PIPELINE_MEGAKERNEL, FTN_PIPELINE_WAVEFRONT = 0, 1, 2
 
 

@@ -810,6 +810,16 @@ class DirectLightingIntegrator:
         self.desc.rr_threshold = 0.0
 
 
+class WhittedIntegrator:
+    """WhittedIntegrator{max_depth} (integrator/whitted.rs:11-13)."""
+
+    def __init__(self, max_depth):
+        self.desc = A.ftn_integrator_desc()
+        self.desc.kind = A.FTN_INTEGRATOR_WHITTED
+        self.desc.max_depth = max_depth
+        self.desc.rr_threshold = 0.0
+
+
 class SamplerIntegrator:
     """SamplerIntegrator{camera, radiance} (integrator/mod.rs:22-25)."""
 

@@ -728,7 +728,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     if (!indexed && sd->kind != FTN_SAMPLER_TILE_SERIAL) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown sampler kind");
     if (!indexed && (sd->first_sample != 0 || (sd->sample_count != 0 && sd->sample_count != sd->samples_per_pixel)))
         return fail(FTN_ERR_INVALID_ARGUMENT, "sample ranges need FTN_SAMPLER_INDEXED");
-    if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
+    if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING && id->kind != FTN_INTEGRATOR_WHITTED) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
     uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
     if (pipeline == FTN_PIPELINE_AUTO) pipeline = (indexed && id->kind == FTN_INTEGRATOR_PATH) ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
     if (pipeline == FTN_PIPELINE_WAVEFRONT && (!indexed || id->kind != FTN_INTEGRATOR_PATH))

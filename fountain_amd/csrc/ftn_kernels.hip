@@ -161,7 +161,7 @@ __device__ inline Rgb path_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max
 #define FTN_OWN_SERIAL (-2147483647 - 1)   /* film_add: single-writer tile walk */
 #define FTN_OWN_NONE (-2147483647)         /* film_add: lane owns no crop pixel */
 template <bool COUNT>
-__device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max_depth, int* err) {
+__device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max_depth, bool whitted, int* err) {
     const DScene& S = T.S;
     Rgb local[FTN_DL_MAX]; Rgb wf[FTN_DL_MAX]; float wc[FTN_DL_MAX], wp[FTN_DL_MAX]; bool owes_t[FTN_DL_MAX];
     int depth = 0; Rgb tail(0.0f); bool have_tail = false;
@@ -176,8 +176,21 @@ __device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t m
         DBsdf B;
         if (!make_bsdf(S.materials[mat], si, false, &B)) { *err = FTN_ERR_UNSUPPORTED; tail = Rgb(0.0f); have_tail = true; break; }
         Rgb rad(0.0f);
-        rad = rad + emitted(S, si, si.wo);
-        rad = rad + uniform_sample_one_light(T, B, si, rng);
+        if (whitted) {                                           /* whitted.rs:42-58: every light, one 2D sample each, no emission term */
+            for (uint32_t li = 0; li < S.n_lights; li++) {
+                const DLight& L = S.lights[li];
+                DLiSample ls = light_sample(S, L, si.hit, rng.next2());
+                if (ls.radiance.is_black() || ls.pdf == 0.0f) continue;
+                Rgb f = bsdf_f(B, si.wo, ls.wi, T_ALL);
+                if (!f.is_black()) {
+                    DRay sr = spawn_ray_to_hit(si.hit, ls.p1);
+                    if (!T.any(sr)) rad = rad + f * ls.radiance * abs_dot(ls.wi, si.shading_n) / ls.pdf;
+                }
+            }
+        } else {
+            rad = rad + emitted(S, si, si.wo);
+            rad = rad + uniform_sample_one_light(T, B, si, rng);
+        }
         local[depth] = rad;
         if (!((uint32_t)depth + 1 < max_depth)) { tail = Rgb(0.0f); have_tail = false; depth++; break; }
         /* specular_reflect: the 2D sample is drawn before the match (mod.rs:52) */
@@ -272,7 +285,7 @@ __device__ inline void render_sample(const RenderParams& P, Tracer<COUNT>& T, co
     V2 p_lens = rng.next2();
     float time_u = rng.next();
     DRay ray = camera_ray(P.C, p_film, p_lens, time_u);
-    Rgb L = (P.integrator_kind == FTN_INTEGRATOR_DIRECT_LIGHTING) ? direct_li(T, ray, rng, P.max_depth, err)
+    Rgb L = (P.integrator_kind != FTN_INTEGRATOR_PATH) ? direct_li(T, ray, rng, P.max_depth, P.integrator_kind == FTN_INTEGRATOR_WHITTED, err)
                                                                   : path_li(T, ray, rng, P.max_depth, P.rr_threshold, err);
     if (L.has_nans()) *err = FTN_ERR_NAN_RADIANCE;       /* check_radiance :285-287 */
     int touched = film_add(F, p_film, L, 1.0f, own_x, own_y, acc);

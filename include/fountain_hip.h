@@ -197,7 +197,8 @@ typedef struct ftn_sampler_desc {
 
 enum {
     FTN_INTEGRATOR_PATH = 0,           /* src/integrator/path.rs:10-96                  */
-    FTN_INTEGRATOR_DIRECT_LIGHTING = 1 /* src/integrator/direct_lighting.rs (UniformSampleOne) */
+    FTN_INTEGRATOR_DIRECT_LIGHTING = 1,/* src/integrator/direct_lighting.rs (UniformSampleOne) */
+    FTN_INTEGRATOR_WHITTED = 2         /* src/integrator/whitted.rs:15-70: every light once, no emission at the hit, specular recursion */
 };
 
 typedef struct ftn_integrator_desc {

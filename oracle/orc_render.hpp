@@ -343,8 +343,18 @@ inline Spectrum direct_li(const Integrator& it, RayDifferential& ray, const Scen
     Bsdf bsdf;
     int r = scattering_functions(isect, ray, scene, false, &bsdf);
     if (r <= 0) { if (r == 0) scene.error.store(FTN_ERR_UNSUPPORTED); return radiance; }   // unimplemented!() :103
-    radiance += scene.emitted_radiance(isect, isect.wo);
-    radiance += uniform_sample_one_light(isect, bsdf, scene, sampler);
+    if (it.kind == FTN_INTEGRATOR_WHITTED) {               // whitted.rs:42-58: every light, one 2D sample each, no emission term
+        for (size_t li = 0; li < scene.lights.size(); li++) {
+            const Light& light = scene.lights[li];
+            LiSample ls = light.sample_incident_radiance(isect.hit, sampler.get_2d());
+            if (ls.radiance.is_black() || ls.pdf == 0.0f) continue;
+            Spectrum f = bsdf.f(isect.wo, ls.wi, BSDF_ALL);
+            if (!f.is_black() && scene.unoccluded(ls.p0, ls.p1)) radiance += f * ls.radiance * abs_dot(ls.wi, isect.shading_n) / ls.pdf;
+        }
+    } else {
+        radiance += scene.emitted_radiance(isect, isect.wo);
+        radiance += uniform_sample_one_light(isect, bsdf, scene, sampler);
+    }
     if (depth + 1 < it.max_depth) {
         radiance += specular_bounce_li(it, ray, isect, bsdf, scene, sampler, depth, BSDF_REFLECTION | BSDF_SPECULAR);
         radiance += specular_bounce_li(it, ray, isect, bsdf, scene, sampler, depth, BSDF_TRANSMISSION | BSDF_SPECULAR);
@@ -367,7 +377,7 @@ inline void render_tile(const SceneData& scene, const Camera& camera, const Film
                 rd.scale_differentials(1.0f / sqrtf((Float)tile_sampler.samples_per_pixel));
                 Spectrum radiance(0.0f);
                 if (ray_weight > 0.0f) {
-                    radiance = (it.kind == FTN_INTEGRATOR_DIRECT_LIGHTING) ? direct_li(it, rd, scene, tile_sampler, 0)
+                    radiance = (it.kind == FTN_INTEGRATOR_DIRECT_LIGHTING || it.kind == FTN_INTEGRATOR_WHITTED) ? direct_li(it, rd, scene, tile_sampler, 0)
                                                                            : path_li(it, rd, scene, tile_sampler);
                     if (radiance.has_nans()) scene.error.store(FTN_ERR_NAN_RADIANCE);   // check_radiance :285-287
                 }

@@ -7,7 +7,7 @@ asserted against the tolerance stated in each test."""
 import numpy as np
 import pytest
 
-from fountain_amd import (DirectLightingIntegrator, Film, FountainError, PathIntegrator, PerspectiveCamera, RandomSampler,
+from fountain_amd import (DirectLightingIntegrator, WhittedIntegrator, Film, FountainError, PathIntegrator, PerspectiveCamera, RandomSampler,
                           SamplerIntegrator, SceneBuilder, _abi as A, make_rays, scenes)
 
 pytestmark = pytest.mark.gpu
@@ -190,6 +190,16 @@ def test_direct_lighting_with_mirror_chain(gpu, orc_det):
     (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, lambda be: scenes.cornell(be, res=48), DirectLightingIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA)
     assert_film_equal(px, pxo, st["spill_samples"], "cornell direct lighting")
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+
+
+@pytest.mark.parametrize("scene", ["cornell", "materials"])
+def test_whitted_integrator(gpu, orc_det, scene):
+    """integrator/whitted.rs: every light sampled once per hit, specular recursion through the mirror sphere; tile-serial and indexed streams"""
+    make = (lambda be: scenes.cornell(be, res=48)) if scene == "cornell" else _materials_scene
+    for smp in (RandomSampler(4, 0, indexed=True), RandomSampler(2, 0)):
+        (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, make, WhittedIntegrator(4), smp, MEGA)
+        assert_film_equal(px, pxo, st["spill_samples"], scene + " whitted")
+        assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
 
 
 # ------------------------------------------------------------------ size-independent properties at BASELINE sizes

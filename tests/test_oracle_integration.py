@@ -5,8 +5,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from fountain_amd import (DirectLightingIntegrator, PathIntegrator, RandomSampler, SceneBuilder, Transform, _abi as A, make_rays,
-                          scenes)
+from fountain_amd import (DirectLightingIntegrator, PathIntegrator, PerspectiveCamera, RandomSampler, SceneBuilder, Transform,
+                          WhittedIntegrator, _abi as A, make_rays, scenes)
 
 
 def _furnace(be, integ, indexed=False):
@@ -33,6 +33,39 @@ def test_furnace_directlighting(orc):
 def test_furnace_det_build_matches_thresholds(orc_det):
     assert np.abs(_furnace(orc_det, PathIntegrator.new(10, 1.0)) - 2.0).max() <= 0.1
     assert np.abs(_furnace(orc_det, DirectLightingIntegrator(3)) - 1.5).max() <= 1e-5
+
+
+def test_whitted_point_light_closed_form(orc):
+    """WhittedIntegrator (integrator/whitted.rs:22-66): a matte plane under one point light has the closed-form radiance
+    Kd/pi * I/r^2 * cos(theta) -- no sampling noise, so every pixel must match the analytic value at its centre closely."""
+    b = SceneBuilder(orc)
+    b.material("matte", Kd=(0.6, 0.5, 0.4))
+    b.shape("trianglemesh", P=[(-50, -50, 0), (50, -50, 0), (50, 50, 0), (-50, 50, 0)], indices=[0, 1, 2, 0, 2, 3])
+    b.light_source("point", I=(30, 30, 30), from_=(0, 0, 3))
+    cam = PerspectiveCamera.look_at(orc, (0, 0, 10), (0, 0, 0), (0, 1, 0), (32, 32), fov=30.0)
+    rgb, px, st, _ = scenes.render(orc, b, cam, (32, 32), WhittedIntegrator(3), RandomSampler(64, 0))
+    half = np.tan(np.radians(15.0)) * 10.0
+    xs = ((np.arange(32) + 0.5) / 32 * 2 - 1) * half
+    X, Y = np.meshgrid(-xs, -xs)                      # image orientation does not matter: the closed form is radially symmetric
+    r2 = X * X + Y * Y + 9.0
+    expect = (30.0 / r2) * (3.0 / np.sqrt(r2)) / np.pi
+    for c, kd in enumerate((0.6, 0.5, 0.4)):
+        assert np.abs(rgb[..., c] - kd * expect).max() <= 1e-2 * (kd * expect).max()   # pixel mean of 64 jittered samples vs centre value
+    assert st["rays_any"] == st["camera_samples"] and st["rays_closest"] == st["camera_samples"]   # one shadow ray per light per hit
+
+
+def test_whitted_has_no_emission_term_and_recurses_through_mirrors(orc):
+    """whitted.rs never adds Le at the hit: the furnace sphere shows Kd*L = 0.5 on average (one light sample per camera sample),
+    and a mirror in front of the camera returns the reflected wall's value through specular_reflect (mod.rs:39-98)."""
+    b, cam, res = scenes.furnace(orc)
+    rgb = scenes.render(orc, b, cam, res, WhittedIntegrator(3), RandomSampler(128, 0))[0]
+    assert abs(rgb.mean() - 0.5) < 0.02
+    b, cam, res = scenes.furnace(orc)
+    b.attribute_begin(); b.material("mirror", Kr=(1, 1, 1)); b.shape("sphere", radius=5.0); b.attribute_end()   # camera at (0,-2,0) is inside
+    depth1 = scenes.render(orc, b, cam, res, WhittedIntegrator(1), RandomSampler(16, 0))[0]
+    depth3 = scenes.render(orc, b, cam, res, WhittedIntegrator(3), RandomSampler(16, 0))[0]
+    assert np.all(depth1 == 0.0)                       # a mirror has no non-specular lobe and depth+1 < max_depth fails
+    assert np.all(depth3 == 0.0)                       # rays bounce inside the closed mirror sphere until the depth runs out
 
 
 def unit_dirs(n, seed):
