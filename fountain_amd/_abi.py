@@ -68,6 +68,23 @@ class ftn_envmap(C.Structure):
     _fields_ = [("width", c_u32), ("height", c_u32), ("texels", C.POINTER(c_f))]
 
 
+FTN_TEX_CONSTANT, FTN_TEX_UV, FTN_TEX_CHECKERBOARD, FTN_TEX_IMAGE = range(4)
+FTN_WRAP_REPEAT, FTN_WRAP_BLACK, FTN_WRAP_CLAMP = range(3)
+
+
+class ftn_texture(C.Structure):
+    _fields_ = [("kind", c_u32), ("is_float", c_u32), ("value", c_f * 3), ("tex1", c_i32), ("tex2", c_i32), ("image", c_i32),
+                ("su", c_f), ("sv", c_f), ("du", c_f), ("dv", c_f)]
+
+
+class ftn_image(C.Structure):
+    _fields_ = [("width", c_u32), ("height", c_u32), ("wrap", c_u32), ("_pad", c_u32), ("texels", C.POINTER(c_f))]
+
+
+class ftn_material_textures(C.Structure):
+    _fields_ = [("a", c_i32), ("b", c_i32), ("s0", c_i32), ("s1", c_i32), ("s2", c_i32), ("_pad", c_i32 * 3)]
+
+
 class ftn_scene_desc(C.Structure):
     _fields_ = [
         ("n_prims", c_u32), ("prims", C.POINTER(ftn_prim)),
@@ -79,6 +96,8 @@ class ftn_scene_desc(C.Structure):
         ("n_area_emit", c_u32), ("area_emit", C.POINTER(c_f)),
         ("n_lights", c_u32), ("lights", C.POINTER(ftn_light)),
         ("n_envmaps", c_u32), ("envmaps", C.POINTER(ftn_envmap)),
+        ("n_textures", c_u32), ("textures", C.POINTER(ftn_texture)), ("material_textures", C.POINTER(ftn_material_textures)),
+        ("n_images", c_u32), ("images", C.POINTER(ftn_image)),
     ]
 
 
@@ -124,7 +143,7 @@ SIZES = {
     "ftn_transform": 128, "ftn_pixel": 16, "ftn_bvh_node": 32, "ftn_prim": 16, "ftn_mesh": 16,
     "ftn_sphere": 288, "ftn_material": 48, "ftn_light": 160, "ftn_envmap": 16, "ftn_camera_desc": 296,
     "ftn_film_desc": 32, "ftn_sampler_desc": 24, "ftn_integrator_desc": 16, "ftn_tile_range": 16,
-    "ftn_render_options": 16, "ftn_stats": 96,
+    "ftn_render_options": 16, "ftn_stats": 96, "ftn_texture": 48, "ftn_image": 24, "ftn_material_textures": 32,
 }
 
 # Every function the header declares (name -> None); used by the symbol-export test.
@@ -140,5 +159,5 @@ DECLARED_FUNCTIONS = [
     "ftn_last_error", "ftn_device_count", "ftn_version", "ftn_test_math",
     "ftn_pbrt_load", "ftn_pbrt_destroy", "ftn_pbrt_scene", "ftn_pbrt_camera", "ftn_pbrt_film",
     "ftn_pbrt_samples_per_pixel", "ftn_pbrt_film_name", "ftn_pbrt_last_error", "ftn_ply_load",
-    "ftn_film_resolve_device", "ftn_exr_write", "ftn_exr_read", "ftn_imageio_last_error",
+    "ftn_test_mipmap_level", "ftn_test_texture_eval", "ftn_film_resolve_device", "ftn_exr_write", "ftn_exr_read", "ftn_imageio_last_error",
 ]

@@ -273,6 +273,11 @@ class SceneBuilder:
         self.spheres = []
         self.lights = []
         self.envmaps = []
+        self.textures = []           # flat ftn_texture array
+        self.images = []             # (texels [h,w,3] float32 after scale/flip, wrap)
+        self.material_textures = []  # one [a, b, s0, s1, s2] per material (-1 = constant)
+        self._spectrum_textures = {}
+        self._float_textures = {}
         # GraphicsState: default material = make_matte(defaults) (pbrt.rs:88-96, constructors.rs:192-196)
         self._state = [dict(material=self._add_material(A.FTN_MAT_MATTE, a=(0.5, 0.5, 0.5), s0=0.0), area=-1, rev=False)]
         self._tf = [Transform.identity(self.be)]
@@ -304,7 +309,77 @@ class SceneBuilder:
     def reverse_orientation(self):
         self._state[-1]["rev"] = True      # sets, does not toggle (pbrt.rs:203-205)
 
-    def _add_material(self, type_, a=(0, 0, 0), b=(0, 0, 0), s0=0.0, s1=0.0, s2=0.0, remap=True):
+    # -- textures (pbrt.rs:362-385, constructors.rs:247-318)
+    def _lookup_texture(self, name):
+        """lookup_texture (pbrt.rs:142-147): spectrum textures first, then float textures -> (index, is_float)."""
+        if name in self._spectrum_textures:
+            return self._spectrum_textures[name], False
+        if name in self._float_textures:
+            return self._float_textures[name], True
+        raise ValueError("TextureError: " + name)
+
+    def _new_texture(self, kind, is_float, value=(0, 0, 0), tex1=-1, tex2=-1, image=-1, mapping=(1.0, 1.0, 0.0, 0.0)):
+        t = A.ftn_texture()
+        t.kind, t.is_float = kind, 1 if is_float else 0
+        t.value = (C.c_float * 3)(*value)
+        t.tex1, t.tex2, t.image = tex1, tex2, image
+        t.su, t.sv, t.du, t.dv = mapping
+        self.textures.append(t)
+        return len(self.textures) - 1
+
+    def _texture_or_const(self, v, is_float):
+        """get_texture_or_const (loaders/mod.rs:213-225): a named texture of the right output type, or a constant."""
+        if isinstance(v, str):
+            idx, f = self._lookup_texture(v)
+            if f != is_float:
+                raise ValueError("ParamError: texture %s has the wrong output type" % v)
+            return idx
+        val = (float(v),) * 3 if is_float else tuple(float(x) for x in v)
+        return self._new_texture(A.FTN_TEX_CONSTANT, is_float, value=val)
+
+    def texture(self, name, ty, cls, **kw):
+        """`Texture "name" "ty" "cls" ...`: (spectrum|color|float, checkerboard), (spectrum|color, uv | imagemap).
+        imagemap takes `filename` (an OpenEXR file) or `texels` ([h, w, 3], first row = top of the image), `wrap`, `scale`."""
+        ty = "spectrum" if ty == "color" else ty
+        if (ty, cls) not in (("spectrum", "checkerboard"), ("spectrum", "uv"), ("float", "checkerboard"), ("spectrum", "imagemap")):
+            raise ValueError("UnknownName(%s %s)" % (ty, cls))
+        is_float = ty == "float"
+        if kw.get("mapping", "uv") != "uv":
+            raise ValueError("Unknown mapping type " + kw["mapping"])
+        mapping = (kw.get("uscale", 1.0), kw.get("vscale", 1.0), kw.get("udelta", 0.0), kw.get("vdelta", 0.0))
+        if cls == "checkerboard":
+            if "tex1" not in kw or "tex2" not in kw:
+                raise ValueError("ParamError: checkerboard needs tex1 and tex2 (constructors.rs:265-266)")
+            t1, t2 = self._texture_or_const(kw["tex1"], is_float), self._texture_or_const(kw["tex2"], is_float)
+            idx = self._new_texture(A.FTN_TEX_CHECKERBOARD, is_float, tex1=t1, tex2=t2, mapping=mapping)
+        elif cls == "uv":
+            idx = self._new_texture(A.FTN_TEX_UV, False, mapping=mapping)
+        else:   # make_imagemap_spect (constructors.rs:295-318) -> load_mipmap (imageio/mod.rs:81-124): scale, flip_y = true
+            if kw.get("gamma", False):
+                raise FountainError(A.FTN_ERR_UNSUPPORTED, "gamma-encoded image maps are not supported (EXR input is linear)")
+            tex = kw.get("texels")
+            if tex is None:
+                tex = read_exr(kw["filename"], self.be)
+            wrap = {"repeat": A.FTN_WRAP_REPEAT, "black": A.FTN_WRAP_BLACK, "clamp": A.FTN_WRAP_CLAMP}[kw.get("wrap", "repeat")]
+            tex = np.asarray(tex, np.float32) * np.float32(kw.get("scale", 1.0))
+            tex = np.ascontiguousarray(tex[::-1])
+            self.images.append((tex, wrap))
+            idx = self._new_texture(A.FTN_TEX_IMAGE, False, image=len(self.images) - 1, mapping=mapping)
+        (self._float_textures if is_float else self._spectrum_textures)[name] = idx
+        return idx
+
+    def _slot(self, v, default, is_float):
+        """get_texture_or_default (loaders/mod.rs:227-236): value -> (constant, texture index).  A texture of the other output
+        type fails the conversion and the default constant is used, as in the reference."""
+        if isinstance(v, str):
+            idx, f = self._lookup_texture(v)
+            return (default, idx) if f == is_float else (default, -1)
+        return (v, -1)
+
+    def _add_material(self, type_, a=(0, 0, 0), b=(0, 0, 0), s0=0.0, s1=0.0, s2=0.0, remap=True, defaults=None):
+        d = defaults or {}
+        (a, ta), (b, tb) = self._slot(a, d.get("a", (0, 0, 0)), False), self._slot(b, d.get("b", (0, 0, 0)), False)
+        (s0, t0), (s1, t1), (s2, t2) = self._slot(s0, d.get("s0", 0.0), True), self._slot(s1, d.get("s1", 0.0), True), self._slot(s2, d.get("s2", 0.0), True)
         m = A.ftn_material()
         m.type = type_
         m.remap_roughness = 1 if remap else 0
@@ -312,27 +387,32 @@ class SceneBuilder:
         m.b = (C.c_float * 3)(*b)
         m.s0, m.s1, m.s2 = s0, s1, s2
         self.materials.append(m)
+        self.material_textures.append([ta, tb, t0, t1, t2])
         return len(self.materials) - 1
 
     def material(self, name, **kw):
         """Defaults from src/loaders/constructors.rs:192-236."""
         if name == "matte":
-            idx = self._add_material(A.FTN_MAT_MATTE, a=kw.get("Kd", (0.5, 0.5, 0.5)), s0=kw.get("sigma", 0.0))
+            idx = self._add_material(A.FTN_MAT_MATTE, a=kw.get("Kd", (0.5, 0.5, 0.5)), s0=kw.get("sigma", 0.0),
+                                     defaults=dict(a=(0.5, 0.5, 0.5), s0=0.0))
         elif name == "mirror":
-            idx = self._add_material(A.FTN_MAT_MIRROR, a=kw.get("Kr", (0.9, 0.9, 0.9)))
+            idx = self._add_material(A.FTN_MAT_MIRROR, a=kw.get("Kr", (0.9, 0.9, 0.9)), defaults=dict(a=(0.9, 0.9, 0.9)))
         elif name == "metal":
             rough = kw.get("roughness", 0.01)
             u = kw.get("uroughness", None)
             v = kw.get("vroughness", None)
             if u is None or v is None:
                 u = v = rough
-            idx = self._add_material(A.FTN_MAT_METAL, a=kw["eta"], b=kw["k"], s1=u, s2=v, remap=kw.get("remaproughness", True))
+            idx = self._add_material(A.FTN_MAT_METAL, a=kw["eta"], b=kw["k"], s1=u, s2=v, remap=kw.get("remaproughness", True),
+                                     defaults=dict(s1=0.01, s2=0.01))
         elif name == "plastic":
             idx = self._add_material(A.FTN_MAT_PLASTIC, a=kw.get("Kd", (0.25, 0.25, 0.25)), b=kw.get("Ks", (0.25, 0.25, 0.25)),
-                                     s1=kw.get("roughness", 0.1), remap=kw.get("remaproughness", True))
+                                     s1=kw.get("roughness", 0.1), remap=kw.get("remaproughness", True),
+                                     defaults=dict(a=(0.25, 0.25, 0.25), b=(0.25, 0.25, 0.25), s1=0.1))
         elif name == "glass":
             idx = self._add_material(A.FTN_MAT_GLASS, a=kw.get("Kr", (1, 1, 1)), b=kw.get("Kt", (1, 1, 1)), s0=kw.get("eta", 1.5),
-                                     s1=kw.get("uroughness", 0.0), s2=kw.get("vroughness", 0.0), remap=kw.get("remaproughness", True))
+                                     s1=kw.get("uroughness", 0.0), s2=kw.get("vroughness", 0.0), remap=kw.get("remaproughness", True),
+                                     defaults=dict(a=(1, 1, 1), b=(1, 1, 1), s0=1.5, s1=0.0, s2=0.0))
         elif name == "none":
             idx = -1
         else:
@@ -491,6 +571,18 @@ class SceneBuilder:
         keep += [envs, self.envmaps]
         d.n_envmaps = len(self.envmaps)
         d.envmaps = envs
+        if self.textures:
+            tarr = (A.ftn_texture * len(self.textures))(*self.textures)
+            marr = (A.ftn_material_textures * max(len(self.materials), 1))()
+            for i, slots in enumerate(self.material_textures):
+                marr[i].a, marr[i].b, marr[i].s0, marr[i].s1, marr[i].s2 = slots
+            iarr = (A.ftn_image * max(len(self.images), 1))()
+            for i, (tex, wrap) in enumerate(self.images):
+                iarr[i].height, iarr[i].width, iarr[i].wrap = tex.shape[0], tex.shape[1], wrap
+                iarr[i].texels = _fptr(tex)
+            keep += [tarr, marr, iarr, self.images]
+            d.n_textures, d.textures, d.material_textures = len(self.textures), tarr, marr
+            d.n_images, d.images = len(self.images), iarr
         return d, keep
 
     def create_scene(self, device=0):

@@ -51,6 +51,9 @@ struct DLight {
     float l2w[16], w2l[16];
 };
 
+/* one ftn_image with its MIP pyramid (mipmap.rs:78-145): level l is lw[l] x lh[l] float4 texels starting at texels[off[l]] */
+struct DImage { uint32_t w, h, wrap, n_levels; uint32_t off[16], lw[16], lh[16]; };
+
 struct DScene {
     const float4* nodes; const float4* geom; const uint4* prim_info;
     const float* N; const float* UV;
@@ -63,11 +66,15 @@ struct DScene {
     const float4* fat;
     float root_lo[3], root_hi[3];
     uint32_t root_is_leaf, n_fat;
+    /* textures (NULL / 0 when every material parameter is a constant): see ftn_texture.h */
+    const ftn_texture* textures; const ftn_material_textures* mtex; const DImage* images; const float4* texels;
+    uint32_t n_textures, _pad2;
 };
 
 struct DCamera {
     float c2w[16]; float r2c[16];
     float shutter_open, shutter_close, lens_radius, focal_dist;
+    float dx_camera[3], dy_camera[3];       /* ray differentials only (camera/mod.rs:100-104) */
 };
 
 struct DRay { V3 o, d; float t_max, time; };
@@ -75,6 +82,8 @@ struct DHit { float t; int prim; float b0, b1, b2; };
 struct DSurfHit { V3 p, p_err, n; float time; };
 /* the part of SurfaceInteraction the integrator consumes */
 struct DSI { DSurfHit hit; V3 wo, shading_n, s_dpdu; int prim; };
+/* the rest of SurfaceInteraction, only needed by textured materials: uv, geometric dpdu/dpdv, shading dndu/dndv */
+struct DSIX { V2 uv; V3 dpdu, dpdv, dndu, dndv; };
 
 /* ------------------------------------------------------------------ spawn rays: interaction.rs:22-58 */
 __device__ inline DRay spawn_ray(const DSurfHit& h, V3 dir) {
@@ -169,7 +178,7 @@ __device__ inline bool tri_uv_degenerate_reject(const DScene& S, int prim, V3 p0
 __device__ inline bool sphere_clipped(const DSphere& s, V3 p, float phi) {
     return (s.z_min > -s.radius && p.z < s.z_min) || (s.z_max < s.radius && p.z > s.z_max) || phi > s.phi_max;
 }
-FTN_DEV_NOINLINE bool sphere_intersect(const DSphere& s, const DRay& wr, float* t_out, DSI* si) {
+FTN_DEV_NOINLINE bool sphere_intersect(const DSphere& s, const DRay& wr, float* t_out, DSI* si, DSIX* ex = nullptr) {
     V3 o_err, d_err;
     V3 ot = m4_point_exact_to_err(s.w2o, wr.o, &o_err);      /* Ray::tf_exact_to_err transform.rs:287-300 */
     V3 dt_ = m4_vector_exact_to_err(s.w2o, wr.d, &d_err);
@@ -220,6 +229,20 @@ FTN_DEV_NOINLINE bool sphere_intersect(const DSphere& s, const DRay& wr, float* 
     si->wo = normalize(m4_vector(s.o2w, -dt_));
     si->shading_n = normalize(m4_normal(s.o2w_inv, n));
     si->s_dpdu = m4_vector(s.o2w, dpdu);
+    if (ex) {                                                   /* sphere.rs:131-160: uv, second derivatives -> dndu/dndv (Weingarten) */
+        ex->uv = V2(phi / s.phi_max, (theta - s.theta_min) / (s.theta_max - s.theta_min));
+        const V3 d2pduu = (-s.phi_max * s.phi_max) * V3(p.x, p.y, 0.0f);
+        const V3 d2pduv = (s.theta_max - s.theta_min) * p.z * s.phi_max * V3(-sin_phi, cos_phi, 0.0f);
+        const V3 d2pdvv = -(s.theta_max - s.theta_min) * (s.theta_max - s.theta_min) * V3(p.x, p.y, p.z);
+        const float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+        const V3 N = normalize(cross(dpdu, dpdv));
+        const float e = dot(N, d2pduu), f = dot(N, d2pduv), g = dot(N, d2pdvv);
+        const float invEGF2 = 1.0f / (E * G - F * F);
+        const V3 dndu = (f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv;
+        const V3 dndv = (g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv;
+        ex->dpdu = m4_vector(s.o2w, dpdu); ex->dpdv = m4_vector(s.o2w, dpdv);
+        ex->dndu = m4_normal(s.o2w_inv, dndu); ex->dndv = m4_normal(s.o2w_inv, dndv);
+    }
     return true;
 }
 
@@ -287,7 +310,25 @@ __device__ inline void load_tri(const DScene& S, int prim, V3* p0, V3* p1, V3* p
     *p0 = V3(g0.x, g0.y, g0.z); *p1 = V3(g1.x, g1.y, g1.z); *p2 = V3(g2.x, g2.y, g2.z); *flags = __float_as_uint(g0.w);
 }
 /* triangle.rs:270-393 */
-FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, float time, DSI* si) {
+/* the barycentric 1/det of the hit test (tri_hit above), which the reference's dndu/dndv use by accident (triangle.rs:361-363) */
+__device__ inline float tri_inv_det(V3 o, V3 d, V3 p0, V3 p1, V3 p2) {
+    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    int kz = max_dimension(vabs(d));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    V3 dir(d.get(kx), d.get(ky), d.get(kz));
+    p0t = V3(p0t.get(kx), p0t.get(ky), p0t.get(kz)); p1t = V3(p1t.get(kx), p1t.get(ky), p1t.get(kz)); p2t = V3(p2t.get(kx), p2t.get(ky), p2t.get(kz));
+    float sx = -dir.x / dir.z, sy = -dir.y / dir.z;
+    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z; p1t.x += sx * p1t.z; p1t.y += sy * p1t.z; p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x, e1 = p2t.x * p0t.y - p2t.y * p0t.x, e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        e0 = (float)((double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x);
+        e1 = (float)((double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x);
+        e2 = (float)((double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x);
+    }
+    return 1.0f / (e0 + e1 + e2);
+}
+FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, float time, DSI* si, DSIX* ex = nullptr, V3 ray_o = V3(0.0f, 0.0f, 0.0f)) {
     V3 p0, p1, p2; uint32_t fl; load_tri(S, h.prim, &p0, &p1, &p2, &fl);
     const uint4 vi = S.prim_info[2 * h.prim + 1];
     const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
@@ -297,12 +338,18 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     float determinant = d02x * d12y - d02y * d12x;
     V3 dpdu, dpdv;
-    if (fabsf(determinant) < 1.0e-8f) {
+    const bool degenerate_uv = fabsf(determinant) < 1.0e-8f;
+    if (degenerate_uv) {
         V3 ng = cross(p2 - p0, p1 - p0);
         coordinate_system(normalize(ng), &dpdu, &dpdv);
     } else {
         float inv = 1.0f / determinant;
         dpdu = (d12y * dp02 - d02y * dp12) * inv;
+        if (ex) dpdv = (-d12x * dp02 + d02x * dp12) * inv;
+    }
+    if (ex) {
+        ex->uv = V2((b0 * u0x + b1 * u1x) + b2 * u2x, (b0 * u0y + b1 * u1y) + b2 * u2y);
+        ex->dpdu = dpdu; ex->dpdv = dpdv; ex->dndu = V3(0.0f, 0.0f, 0.0f); ex->dndv = V3(0.0f, 0.0f, 0.0f);
     }
     float xs = fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x);
     float ys = fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y);
@@ -326,19 +373,31 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
         si->s_dpdu = ss;
         sn = ns;
         n = faceforward(n, sn);
+        if (ex) {                                                /* triangle.rs:351-366 */
+            const V3 dn1 = n0 - n2, dn2 = n1 - n2;
+            if (degenerate_uv) {
+                const V3 dn = cross(n2 - n0, n1 - n0);
+                if (len2(dn) == 0.0f) { ex->dndu = V3(0.0f, 0.0f, 0.0f); ex->dndv = V3(0.0f, 0.0f, 0.0f); }
+                else coordinate_system(dn, &ex->dndu, &ex->dndv);
+            } else {
+                const float inv_det = tri_inv_det(ray_o, ray_d, p0, p1, p2);     /* sic: the barycentric determinant */
+                ex->dndu = (d12y * dn1 - d02y * dn2) * inv_det;
+                ex->dndv = (-d12x * dn1 + d02x * dn2) * inv_det;
+            }
+        }
     }
     si->hit.n = n; si->shading_n = sn; si->prim = h.prim;
 }
-__device__ inline bool make_interaction(const DScene& S, const DHit& h, const DRay& ray_before_hit, DSI* si) {
+__device__ inline bool make_interaction(const DScene& S, const DHit& h, const DRay& ray_before_hit, DSI* si, DSIX* ex = nullptr) {
     const float4 g0 = S.geom[3 * h.prim];
     if (__float_as_uint(g0.w) & GF_KIND_SPHERE) {
         DRay r = ray_before_hit; r.t_max = FTN_INF;   /* same root selection as at traversal time */
         float t; const float4 g1 = S.geom[3 * h.prim + 1];
-        bool ok = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, si);
+        bool ok = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, si, ex);
         si->prim = h.prim;
         return ok;
     }
-    tri_interaction(S, h, ray_before_hit.d, ray_before_hit.time, si);
+    tri_interaction(S, h, ray_before_hit.d, ray_before_hit.time, si, ex, ray_before_hit.o);
     return true;
 }
 

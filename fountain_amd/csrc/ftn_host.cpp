@@ -10,6 +10,7 @@
  */
 #include "ftn_kernels.h"
 #include "ftn_wavefront.h"
+#include "ftn_texture.h"
 
 #include <algorithm>
 #include <chrono>
@@ -450,12 +451,67 @@ template <class T> struct DevBuf {
 
 }  // namespace
 
+/* ------------------------------------------------------------------ MIPMap::<Spectrum>::new (mipmap.rs:78-145): level 0 = the image, every further
+ * level = the previous one shrunk to max(1, w/2) x max(1, h/2) by the `resize` crate's Triangle filter (resize 0.4.3, un-vendored:
+ * its published algorithm restated -- DESIGN.md "parity unpinned" note).  Separable: per output sample a coefficient line
+ * (support 1.0 scaled by the shrink ratio, taps clamped to the image, normalised); rows first (H1 -> H2, into a transposed f32
+ * buffer), then columns (W1 -> W2); plain f32 multiply-adds in tap order. */
+namespace {
+struct MipLevelHost { uint32_t w, h; std::vector<float> rgb; };
+struct TapLine { size_t first; std::vector<float> w; };
+static std::vector<TapLine> triangle_taps(size_t n_src, size_t n_dst) {
+    const float ratio = (float)n_src / (float)n_dst;
+    const float scale = ratio > 1.0f ? ratio : 1.0f;
+    const float radius = ceilf(scale);                                        /* support (1.0) * scale */
+    std::vector<TapLine> lines(n_dst);
+    for (size_t j = 0; j < n_dst; j++) {
+        const float centre = ((float)j + 0.5f) * ratio - 0.5f;
+        long lo = (long)ceilf(centre - radius), hi = (long)floorf(centre + radius);
+        lo = std::min<long>(std::max<long>(lo, 0), (long)n_src - 1); hi = std::min<long>(std::max<long>(hi, 0), (long)n_src - 1);
+        float total = 0.0f;
+        for (long k = lo; k <= hi; k++) total += fmaxf(1.0f - fabsf(((float)k - centre) / scale), 0.0f);
+        lines[j].first = (size_t)lo;
+        for (long k = lo; k <= hi; k++) lines[j].w.push_back(fmaxf(1.0f - fabsf(((float)k - centre) / scale), 0.0f) / total);
+    }
+    return lines;
+}
+static void shrink_triangle(uint32_t w1, uint32_t h1, uint32_t w2, uint32_t h2, const std::vector<float>& src, std::vector<float>* dst) {
+    const std::vector<TapLine> across = triangle_taps(w1, w2), down = triangle_taps(h1, h2);
+    std::vector<float> mid((size_t)w1 * h2 * 3);                              /* [x1][y2] */
+    for (size_t x = 0; x < w1; x++)
+        for (size_t y = 0; y < h2; y++) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f; const TapLine& L = down[y];
+            for (size_t k = 0; k < L.w.size(); k++) { const float* q = &src[((L.first + k) * w1 + x) * 3]; a0 += q[0] * L.w[k]; a1 += q[1] * L.w[k]; a2 += q[2] * L.w[k]; }
+            float* o = &mid[(x * h2 + y) * 3]; o[0] = a0; o[1] = a1; o[2] = a2;
+        }
+    dst->assign((size_t)w2 * h2 * 3, 0.0f);
+    for (size_t y = 0; y < h2; y++)
+        for (size_t x = 0; x < w2; x++) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f; const TapLine& L = across[x];
+            for (size_t k = 0; k < L.w.size(); k++) { const float* q = &mid[((L.first + k) * h2 + y) * 3]; a0 += q[0] * L.w[k]; a1 += q[1] * L.w[k]; a2 += q[2] * L.w[k]; }
+            float* o = &(*dst)[(y * w2 + x) * 3]; o[0] = a0; o[1] = a1; o[2] = a2;
+        }
+}
+static void build_mip_pyramid(uint32_t w, uint32_t h, const float* rgb, std::vector<MipLevelHost>* out) {
+    out->clear();
+    MipLevelHost l0; l0.w = w; l0.h = h; l0.rgb.assign(rgb, rgb + (size_t)w * h * 3); out->push_back(l0);
+    uint32_t big = std::max(w, h); int n_levels = 1; while (big >>= 1) n_levels++;          /* 1 + log2_usize(max(w, h)) */
+    for (int l = 1; l < n_levels; l++) {
+        const MipLevelHost& prev = out->back();
+        MipLevelHost nx; nx.w = std::max<uint32_t>(1, prev.w / 2); nx.h = std::max<uint32_t>(1, prev.h / 2);
+        shrink_triangle(prev.w, prev.h, nx.w, nx.h, prev.rgb, &nx.rgb);
+        out->push_back(std::move(nx));
+    }
+}
+}  // namespace
+
 struct ftn_scene {
     int device = 0;
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
     DevBuf<float4> nodes, geom, fat; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
     DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc;
+    DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
     DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
     WavefrontState* wf = nullptr;
@@ -463,6 +519,7 @@ struct ftn_scene {
     ~ftn_scene() {
         nodes.release(); geom.release(); fat.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
+        textures.release(); mtex.release(); images.release(); texels.release();
         accA.release(); accB.release(); accC.release(); tiles.release(); stats.release();
         wavefront_destroy(wf);
     }
@@ -536,18 +593,14 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         o.reverse_orientation = s.reverse_orientation; o._pad = 0;
     }
     if ((rc = sc->spheres.upload(sph.data(), sph.size()))) return rc;
-    /* materials: evaluate the constant-per-material parts of compute_scattering_functions once */
+    /* materials: evaluate the constant-per-material parts of compute_scattering_functions once (textured materials stay raw and are
+     * finalized per hit by material_resolve, ftn_texture.h) */
     std::vector<ftn_material> mats(d->materials, d->materials + d->n_materials);
-    for (auto& m : mats) {
-        auto r2a = [](float roughness) {                                          /* roughness_to_alpha microfacet.rs:40-45 */
-            float x = ftn_det::logf_det(fmax_(roughness, 1.0e-3f));
-            return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
-        };
-        if (m.type == FTN_MAT_MATTE) {                                            /* matte.rs:39-50, OrenNayar::new reflection/mod.rs:260-267 */
-            m.s0 = clampf(m.s0, 0.0f, 90.0f);
-            if (m.s0 != 0.0f) { float sg = m.s0 * (float)(3.14159265358979323846 / 180.0); float s2 = sg * sg; m.s1 = 1.0f - (s2 / (2.0f * (s2 + 0.33f))); m.s2 = 0.45f * s2 / (s2 + 0.09f); }
-        } else if (m.type == FTN_MAT_METAL || m.type == FTN_MAT_GLASS) { if (m.remap_roughness) { m.s1 = r2a(m.s1); m.s2 = r2a(m.s2); m.remap_roughness = 0; } }
-        else if (m.type == FTN_MAT_PLASTIC) { if (m.remap_roughness) { m.s1 = r2a(m.s1); m.remap_roughness = 0; } }
+    const bool has_tex = d->n_textures != 0 && d->textures != nullptr;
+    for (size_t i = 0; i < mats.size(); i++) {
+        bool textured = false;
+        if (has_tex && d->material_textures) { const ftn_material_textures& mt = d->material_textures[i]; textured = (mt.a & mt.b & mt.s0 & mt.s1 & mt.s2) >= 0; }
+        if (!textured) material_finalize(mats[i]);
     }
     if ((rc = sc->materials.upload(mats.data(), mats.size()))) return rc;
     /* lights */
@@ -617,6 +670,36 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
     sc->stack_entries = std::max<uint32_t>(hs.max_depth, 1u);
     if ((rc = sc->stats.alloc_zero(1))) return rc;
+    if (has_tex) {                                               /* textures + MIP pyramids */
+        const int nt = (int)d->n_textures, ni = d->images ? (int)d->n_images : 0;
+        for (int i = 0; i < nt; i++) {
+            const ftn_texture& t = d->textures[i];
+            if (t.kind > FTN_TEX_IMAGE) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown texture kind");
+            if (t.kind == FTN_TEX_CHECKERBOARD && (t.tex1 < 0 || t.tex1 >= nt || t.tex2 < 0 || t.tex2 >= nt)) return fail(FTN_ERR_INVALID_ARGUMENT, "checkerboard child texture out of range");
+            if (t.kind == FTN_TEX_IMAGE && (t.image < 0 || t.image >= ni)) return fail(FTN_ERR_INVALID_ARGUMENT, "image index out of range");
+        }
+        std::vector<ftn_material_textures> mt(d->n_materials);
+        for (uint32_t i = 0; i < d->n_materials; i++) {
+            if (d->material_textures) mt[i] = d->material_textures[i]; else { mt[i].a = mt[i].b = mt[i].s0 = mt[i].s1 = mt[i].s2 = -1; }
+            for (int32_t id : {mt[i].a, mt[i].b, mt[i].s0, mt[i].s1, mt[i].s2}) if (id >= nt) return fail(FTN_ERR_INVALID_ARGUMENT, "material texture index out of range");
+        }
+        std::vector<DImage> imgs((size_t)ni); std::vector<float4> texels;
+        for (int i = 0; i < ni; i++) {
+            const ftn_image& im = d->images[i];
+            if (im.width == 0 || im.height == 0 || !im.texels || im.wrap > FTN_WRAP_CLAMP) return fail(FTN_ERR_INVALID_ARGUMENT, "bad image");
+            std::vector<MipLevelHost> pyr; build_mip_pyramid(im.width, im.height, im.texels, &pyr);
+            if (pyr.size() > 16) return fail(FTN_ERR_UNSUPPORTED, "image larger than 32768 texels on a side");
+            DImage& D2 = imgs[(size_t)i]; memset(&D2, 0, sizeof(D2));
+            D2.w = im.width; D2.h = im.height; D2.wrap = im.wrap; D2.n_levels = (uint32_t)pyr.size();
+            for (size_t l = 0; l < pyr.size(); l++) {
+                D2.off[l] = (uint32_t)texels.size(); D2.lw[l] = pyr[l].w; D2.lh[l] = pyr[l].h;
+                for (size_t k = 0; k < (size_t)pyr[l].w * pyr[l].h; k++) texels.push_back(make_float4(pyr[l].rgb[3 * k], pyr[l].rgb[3 * k + 1], pyr[l].rgb[3 * k + 2], 0.0f));
+            }
+        }
+        if ((rc = sc->textures.upload(d->textures, (size_t)nt)) || (rc = sc->mtex.upload(mt.data(), mt.size())) || (rc = sc->images.upload(imgs.data(), imgs.size())) ||
+            (rc = sc->texels.upload(texels.data(), texels.size()))) return rc;
+        D.textures = sc->textures.p; D.mtex = sc->mtex.p; D.images = sc->images.p; D.texels = sc->texels.p; D.n_textures = (uint32_t)nt;
+    }
     return FTN_OK;
 }
 
@@ -752,6 +835,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     P.S = s->d;
     memcpy(P.C.c2w, cam->camera_to_world.m, 64); memcpy(P.C.r2c, cam->raster_to_camera.m, 64);
     P.C.shutter_open = cam->shutter_open; P.C.shutter_close = cam->shutter_close; P.C.lens_radius = cam->lens_radius; P.C.focal_dist = cam->focal_dist;
+    for (int k = 0; k < 3; k++) { P.C.dx_camera[k] = cam->dx_camera[k]; P.C.dy_camera[k] = cam->dy_camera[k]; }
     for (int i = 0; i < 4; i++) P.crop[i] = film->crop[i];
     P.radius[0] = film->filter_radius[0]; P.radius[1] = film->filter_radius[1]; P.inv_radius[0] = 1.0f / P.radius[0]; P.inv_radius[1] = 1.0f / P.radius[1];
     P.sampler_kind = sd->kind; P.spp = sd->samples_per_pixel; P.seed = sd->seed;
@@ -800,6 +884,29 @@ int ftn_test_math(int which, const float* x, const float* y, size_t n, float* ou
     launch_test_math(which, dx.p, dy.p, n, dout.p, 0);
     hipError_t e = hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost);
     dx.release(); dy.release(); dout.release();
+    if (e != hipSuccess) return fail(FTN_ERR_NO_DEVICE, hipGetErrorString(e));
+    return FTN_OK;
+}
+
+/* test hooks for the texture path: a pyramid level as built on the host; Texture::evaluate on the device for arrays of (uv, dudx, dvdx, dudy, dvdy) */
+int ftn_test_mipmap_level(uint32_t width, uint32_t height, const float* texels, uint32_t level, uint32_t* level_w, uint32_t* level_h, float* rgb_out) {
+    if (!texels || width == 0 || height == 0) return fail(FTN_ERR_INVALID_ARGUMENT, "bad image");
+    std::vector<MipLevelHost> pyr; build_mip_pyramid(width, height, texels, &pyr);
+    if (level >= pyr.size()) return fail(FTN_ERR_INVALID_ARGUMENT, "no such level");
+    if (level_w) *level_w = pyr[level].w;
+    if (level_h) *level_h = pyr[level].h;
+    if (rgb_out) memcpy(rgb_out, pyr[level].rgb.data(), pyr[level].rgb.size() * sizeof(float));
+    return FTN_OK;
+}
+int ftn_test_texture_eval(const ftn_scene* cs, int32_t texture, const float* uv_diffs6, size_t n, float* rgb_out) {
+    if (!cs || !uv_diffs6 || !rgb_out) return fail(FTN_ERR_INVALID_ARGUMENT, "null argument");
+    if (texture < 0 || (uint32_t)texture >= cs->d.n_textures) return fail(FTN_ERR_INVALID_ARGUMENT, "texture index out of range");
+    int rc = set_device(cs->device); if (rc) return rc;
+    DevBuf<float> din, dout;
+    if ((rc = din.upload(uv_diffs6, 6 * n)) || (rc = dout.alloc_zero(3 * n))) { din.release(); dout.release(); return rc; }
+    launch_test_texture_eval(cs->d, texture, din.p, n, dout.p, 0);
+    hipError_t e = hipMemcpy(rgb_out, dout.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+    din.release(); dout.release();
     if (e != hipSuccess) return fail(FTN_ERR_NO_DEVICE, hipGetErrorString(e));
     return FTN_OK;
 }

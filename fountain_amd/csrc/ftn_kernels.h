@@ -37,6 +37,7 @@ void launch_trace_batch(const DScene& S, const float* rays, size_t n, int mode /
                         float* bary, unsigned char* occluded, float* out24, DevStats* stats, uint32_t stack_entries, bool count, hipStream_t stream);
 
 void launch_spectrum_buffer(const ftn_pixel* device_pixels, size_t n, float* device_rgb, hipStream_t stream);
+void launch_test_texture_eval(const DScene& S, int texture, const float* uv_diffs6, size_t n, float* rgb_out, hipStream_t stream);
 void launch_test_math(int which, const float* x, const float* y, size_t n, float* out, hipStream_t stream);
 
 }  // namespace ftn

@@ -15,6 +15,7 @@
  * the BVH's depth, so LDS per workgroup = depth * 256 * 4 bytes.
  */
 #include "ftn_kernels.h"
+#include "ftn_texture.h"
 
 namespace ftn {
 
@@ -108,8 +109,10 @@ __device__ inline Rgb emitted(const DScene& S, const DSI& si, V3 w) {          /
 }
 
 /* ------------------------------------------------------------------ PathIntegrator::incident_radiance: path.rs:25-95 */
-template <bool COUNT>
-__device__ inline Rgb path_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max_depth, float rr_threshold, int* err) {
+/* TEX: some material parameter is a texture.  `rd` is the camera ray's differential; the path integrator hands it on unchanged at
+ * every bounce (path.rs:73, :79), so texture footprints after the first hit come from the CAMERA offsets rays, as in the reference. */
+template <bool COUNT, bool TEX>
+__device__ inline Rgb path_li(Tracer<COUNT>& T, DRay ray, const DRayDiff& rd, Rng& rng, uint32_t max_depth, float rr_threshold, int* err) {
     const DScene& S = T.S;
     Rgb L(0.0f), beta(1.0f);
     uint32_t bounces = 0; bool specular_bounce = false;
@@ -126,7 +129,13 @@ __device__ inline Rgb path_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max
         const int mat = (int)S.prim_info[2 * si.prim].x;
         if (mat >= 0) {
             DBsdf B;
-            if (!make_bsdf(S.materials[mat], si, true, &B)) { *err = FTN_ERR_UNSUPPORTED; break; }
+            ftn_material mloc; const ftn_material* mp = &S.materials[mat];
+            if (TEX && material_is_textured(S, mat)) {            /* Texture::evaluate(si) for every textured parameter */
+                DSIX ex; DSI s2; make_interaction(S, h, ray0, &s2, &ex);
+                const DTexDiffs td = compute_tex_diffs(si.hit.p, si.hit.n, ex.dpdu, ex.dpdv, rd);
+                mloc = material_resolve(S, mat, ex.uv, td); mp = &mloc;
+            }
+            if (!make_bsdf(*mp, si, true, &B)) { *err = FTN_ERR_UNSUPPORTED; break; }
             if (bsdf_num(B, T_ALL & ~T_SPECULAR) > 0) {
                 Rgb direct = beta * uniform_sample_one_light(T, B, si, rng);
                 L = L + direct;
@@ -160,8 +169,8 @@ __device__ inline Rgb path_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max
 #define FTN_DL_MAX 8
 #define FTN_OWN_SERIAL (-2147483647 - 1)   /* film_add: single-writer tile walk */
 #define FTN_OWN_NONE (-2147483647)         /* film_add: lane owns no crop pixel */
-template <bool COUNT>
-__device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t max_depth, bool whitted, int* err) {
+template <bool COUNT, bool TEX>
+__device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, DRayDiff rd, Rng& rng, uint32_t max_depth, bool whitted, int* err) {
     const DScene& S = T.S;
     Rgb local[FTN_DL_MAX]; Rgb wf[FTN_DL_MAX]; float wc[FTN_DL_MAX], wp[FTN_DL_MAX]; bool owes_t[FTN_DL_MAX];
     int depth = 0; Rgb tail(0.0f); bool have_tail = false;
@@ -174,7 +183,15 @@ __device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t m
         const int mat = (int)S.prim_info[2 * si.prim].x;
         if (mat < 0) { *err = FTN_ERR_UNSUPPORTED; tail = Rgb(0.0f); have_tail = true; break; }   /* unimplemented!() :103 */
         DBsdf B;
-        if (!make_bsdf(S.materials[mat], si, false, &B)) { *err = FTN_ERR_UNSUPPORTED; tail = Rgb(0.0f); have_tail = true; break; }
+        ftn_material mloc; const ftn_material* mp = &S.materials[mat];
+        DSIX ex; DTexDiffs td; float bsdf_eta = 1.0f;
+        if (TEX) {                                             /* differentials follow the specular chain (mod.rs:58-84, :119-163) */
+            DSI s2; make_interaction(S, h, ray0, &s2, &ex);
+            td = compute_tex_diffs(si.hit.p, si.hit.n, ex.dpdu, ex.dpdv, rd);
+            if (material_is_textured(S, mat)) { mloc = material_resolve(S, mat, ex.uv, td); mp = &mloc; }
+            if (mp->type == FTN_MAT_GLASS) bsdf_eta = mp->s0;  /* Bsdf::new(si, eta): glass.rs:60 */
+        }
+        if (!make_bsdf(*mp, si, false, &B)) { *err = FTN_ERR_UNSUPPORTED; tail = Rgb(0.0f); have_tail = true; break; }
         Rgb rad(0.0f);
         if (whitted) {                                           /* whitted.rs:42-58: every light, one 2D sample each, no emission term */
             for (uint32_t li = 0; li < S.n_lights; li++) {
@@ -202,6 +219,7 @@ __device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t m
         if (has_r && has_t) { *err = FTN_ERR_UNSUPPORTED; depth++; break; }
         if (has_r) {
             wf[depth] = sr.f; wc[depth] = fabsf(dot(sr.wi, si.shading_n)); wp[depth] = sr.pdf;
+            if (TEX) rd = specular_diff(true, rd, si.hit.p, si.wo, sr.wi, si.shading_n, ex.dndu, ex.dndv, td, bsdf_eta);
             ray = spawn_ray(si.hit, sr.wi);
             depth++;
             continue;
@@ -213,6 +231,7 @@ __device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, Rng& rng, uint32_t m
             if (bsdf_sample(B, si.wo, ut, T_TRANS | T_SPECULAR, &stt) && !(abs_dot(stt.wi, si.shading_n) == 0.0f)) {
                 wf[depth] = stt.f; wc[depth] = fabsf(dot(stt.wi, si.shading_n)); wp[depth] = stt.pdf;
                 local[depth] = local[depth] + Rgb(0.0f);      /* radiance += specular_reflect (= 0) */
+                if (TEX) rd = specular_diff(false, rd, si.hit.p, si.wo, stt.wi, si.shading_n, ex.dndu, ex.dndv, td, bsdf_eta);
                 ray = spawn_ray(si.hit, stt.wi);
                 depth++;
                 continue;
@@ -277,7 +296,7 @@ __device__ inline void make_film_ctx(const RenderParams& P, const DTile& t, Film
 }
 
 /* ------------------------------------------------------------------ one camera sample: render_tile's inner loop body (mod.rs:244-274) */
-template <bool COUNT>
+template <bool COUNT, bool TEX>
 __device__ inline void render_sample(const RenderParams& P, Tracer<COUNT>& T, const FilmCtx& F, Rng& rng, int px, int py, int own_x, int own_y,
                                      float4* acc, int* err) {
     V2 j = rng.next2();
@@ -285,15 +304,17 @@ __device__ inline void render_sample(const RenderParams& P, Tracer<COUNT>& T, co
     V2 p_lens = rng.next2();
     float time_u = rng.next();
     DRay ray = camera_ray(P.C, p_film, p_lens, time_u);
-    Rgb L = (P.integrator_kind != FTN_INTEGRATOR_PATH) ? direct_li(T, ray, rng, P.max_depth, P.integrator_kind == FTN_INTEGRATOR_WHITTED, err)
-                                                                  : path_li(T, ray, rng, P.max_depth, P.rr_threshold, err);
+    DRayDiff rd; rd.has = false;
+    if (TEX) rd = camera_ray_diff(P.C, p_film, p_lens, ray, 1.0f / sqrtf((float)P.spp));     /* generate_ray_differential + scale_differentials (mod.rs:252-254) */
+    Rgb L = (P.integrator_kind != FTN_INTEGRATOR_PATH) ? direct_li<COUNT, TEX>(T, ray, rd, rng, P.max_depth, P.integrator_kind == FTN_INTEGRATOR_WHITTED, err)
+                                                                  : path_li<COUNT, TEX>(T, ray, rd, rng, P.max_depth, P.rr_threshold, err);
     if (L.has_nans()) *err = FTN_ERR_NAN_RADIANCE;       /* check_radiance :285-287 */
     int touched = film_add(F, p_film, L, 1.0f, own_x, own_y, acc);
     T.lc.cam++;
     if (touched != 1) T.lc.spill++;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool TEX>
 __global__ void __launch_bounds__(256) k_render_mega(RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     const DTile tile = P.tiles[blockIdx.x];
@@ -309,7 +330,7 @@ __global__ void __launch_bounds__(256) k_render_mega(RenderParams P) {
             if (in_crop) { ai = film_idx(F, px, py); acc = P.accA[ai]; }
             for (uint32_t s = P.first_sample; s < P.last_sample; s++) {
                 Rng rng; rng.seed(indexed_key(P.seed, px, py, s));
-                render_sample(P, T, F, rng, px, py, in_crop ? px : FTN_OWN_NONE, py, &acc, &err);
+                render_sample<COUNT, TEX>(P, T, F, rng, px, py, in_crop ? px : FTN_OWN_NONE, py, &acc, &err);
             }
             if (in_crop) P.accA[ai] = acc;
         }
@@ -319,7 +340,7 @@ __global__ void __launch_bounds__(256) k_render_mega(RenderParams P) {
         for (int py = tile.y0; py < tile.y1; py++)
             for (int px = tile.x0; px < tile.x1; px++)
                 for (uint32_t s = 0; s < P.spp; s++)
-                    render_sample(P, T, F, rng, px, py, FTN_OWN_SERIAL, 0, &dummy, &err);
+                    render_sample<COUNT, TEX>(P, T, F, rng, px, py, FTN_OWN_SERIAL, 0, &dummy, &err);
     }
     flush_counters(P.stats, lc, COUNT);
     if (err) atomicCAS(&P.stats->error, 0, err);
@@ -328,8 +349,9 @@ __global__ void __launch_bounds__(256) k_render_mega(RenderParams P) {
 void launch_render_mega(const RenderParams& p, bool count, hipStream_t stream) {
     if (p.n_tiles == 0) return;
     size_t lds = (size_t)p.stack_entries * 256 * sizeof(uint32_t);
-    if (count) hipLaunchKernelGGL(k_render_mega<true>, dim3(p.n_tiles), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(k_render_mega<false>, dim3(p.n_tiles), dim3(256), lds, stream, p);
+    const bool tex = p.S.n_textures != 0;
+    if (tex) { if (count) hipLaunchKernelGGL((k_render_mega<true, true>), dim3(p.n_tiles), dim3(256), lds, stream, p); else hipLaunchKernelGGL((k_render_mega<false, true>), dim3(p.n_tiles), dim3(256), lds, stream, p); }
+    else { if (count) hipLaunchKernelGGL((k_render_mega<true, false>), dim3(p.n_tiles), dim3(256), lds, stream, p); else hipLaunchKernelGGL((k_render_mega<false, false>), dim3(p.n_tiles), dim3(256), lds, stream, p); }
 }
 
 /* ------------------------------------------------------------------ Film::merge_film_tile: film.rs:121-132.  pixel.xyz += to_xyz(tile sum) per contributing tile */
@@ -373,6 +395,20 @@ void launch_spectrum_buffer(const ftn_pixel* device_pixels, size_t n, float* dev
     if (n == 0) return;
     unsigned grid = (unsigned)((n + 255) / 256); if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(k_spectrum_buffer, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(device_pixels), device_rgb, n);
+}
+
+/* ------------------------------------------------------------------ test hook: Texture::evaluate for arrays of (u, v, dudx, dvdx, dudy, dvdy) */
+__global__ void __launch_bounds__(256) k_test_texture_eval(DScene S, int texture, const float* __restrict__ in6, size_t n, float* __restrict__ out3) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    DTexDiffs td; td.dpdx = V3(0.0f, 0.0f, 0.0f); td.dpdy = td.dpdx;
+    td.dudx = in6[6 * i + 2]; td.dvdx = in6[6 * i + 3]; td.dudy = in6[6 * i + 4]; td.dvdy = in6[6 * i + 5];
+    const Rgb c = tex_eval(S, texture, V2(in6[6 * i], in6[6 * i + 1]), td);
+    out3[3 * i] = c.r; out3[3 * i + 1] = c.g; out3[3 * i + 2] = c.b;
+}
+void launch_test_texture_eval(const DScene& S, int texture, const float* uv_diffs6, size_t n, float* rgb_out, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_test_texture_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, texture, uv_diffs6, n, rgb_out);
 }
 
 /* ------------------------------------------------------------------ batch Scene::intersect / intersect_test / full interaction */

@@ -6,7 +6,7 @@
  * call by call are bit-identical.  Reference quirks kept: `ReverseOrientation` sets (does not toggle) the flag (pbrt.rs:203-205);
  * plastic reads "ks" in lower case (constructors.rs:232); point/distant lights ignore the CTM; Integrator / PixelFilter /
  * Accelerator statements are ignored (pbrt.rs:528-530); ObjectBegin/End are unimplemented in the reference -> FTN_ERR_UNSUPPORTED.
- * Only constant textures exist on this path: a "texture" parameter reports FTN_ERR_UNSUPPORTED.
+ * Texture statements: checkerboard (spectrum / float), uv and imagemap (OpenEXR files) as in pbrt.rs:362-385.
  */
 #include "../../include/fountain_hip.h"
 
@@ -67,6 +67,8 @@ struct ftn_pbrt {
     std::map<std::string, int> named_materials;
     std::vector<ftn_prim> prims; std::vector<uint32_t> tri_indices, tri_mesh; std::vector<float> P, N, UV; bool any_n = false, any_uv = false;
     std::vector<ftn_mesh> meshes; std::vector<ftn_sphere> spheres; std::vector<ftn_material> materials; std::vector<float> area_emit;
+    std::vector<ftn_texture> textures; std::vector<ftn_material_textures> mtex; std::map<std::string, int> spectrum_textures, float_textures;
+    struct Img { uint32_t w, h, wrap; std::vector<float> texels; }; std::vector<Img> image_store; std::vector<ftn_image> images;
     std::vector<ftn_light> lights; std::vector<ftn_envmap> envmaps; struct Env { uint32_t w, h; std::vector<float> texels; }; std::vector<Env> env_store;
     ftn_scene_desc desc;
 };
@@ -98,20 +100,57 @@ float getf(const ParamSet& ps, const char* n, float def) { auto it = ps.find(n);
 int geti(const ParamSet& ps, const char* n, int def) { auto it = ps.find(n); return (it != ps.end() && it->second.type == "integer" && !it->second.i.empty()) ? it->second.i[0] : def; }
 bool getb(const ParamSet& ps, const char* n, bool def) { auto it = ps.find(n); return (it != ps.end() && it->second.type == "bool" && !it->second.b.empty()) ? it->second.b[0] != 0 : def; }
 bool is_spectrum(const Param& p) { return p.type == "rgb" || p.type == "color"; }
-/* get_texture_or_default::<Spectrum>: an rgb value, else the default; textures are unsupported */
-int get_rgb(ftn_pbrt* S, const ParamSet& ps, const char* n, const float def[3], float out[3]) {
+/* lookup_texture (pbrt.rs:142-147): spectrum textures first, then float textures */
+int lookup_texture(ftn_pbrt* S, const std::string& name, int* idx, bool* is_float) {
+    auto a = S->spectrum_textures.find(name);
+    if (a != S->spectrum_textures.end()) { *idx = a->second; *is_float = false; return FTN_OK; }
+    auto b = S->float_textures.find(name);
+    if (b != S->float_textures.end()) { *idx = b->second; *is_float = true; return FTN_OK; }
+    return fail(S, FTN_ERR_INVALID_ARGUMENT, "TextureError: " + name);
+}
+/* make_param_set resolves every "texture" parameter up front (pbrt.rs:114-131): an unknown name fails the statement */
+int check_texture_params(ftn_pbrt* S, const ParamSet& ps) {
+    for (const auto& kv : ps) if (kv.second.type == "texture") { int i; bool f; if (kv.second.s.empty()) return fail(S, FTN_ERR_INVALID_ARGUMENT, "empty texture parameter"); int rc = lookup_texture(S, kv.second.s[0], &i, &f); if (rc) return rc; }
+    return FTN_OK;
+}
+/* get_texture_or_default::<Spectrum> (loaders/mod.rs:227-236): an rgb constant, a spectrum texture, else the default (a float
+ * texture fails the conversion and falls back to the default as well) */
+int get_rgb(ftn_pbrt* S, const ParamSet& ps, const char* n, const float def[3], float out[3], int32_t* tex) {
     auto it = ps.find(n);
-    out[0] = def[0]; out[1] = def[1]; out[2] = def[2];
+    out[0] = def[0]; out[1] = def[1]; out[2] = def[2]; *tex = -1;
     if (it == ps.end()) return FTN_OK;
-    if (it->second.type == "texture") return fail(S, FTN_ERR_UNSUPPORTED, std::string("non-constant texture for '") + n + "' is outside the hot-path scope");
+    if (it->second.type == "texture") { int i; bool f; int rc = lookup_texture(S, it->second.s[0], &i, &f); if (rc) return rc; if (!f) *tex = i; return FTN_OK; }
     if (is_spectrum(it->second) && it->second.f.size() >= 3) { out[0] = it->second.f[0]; out[1] = it->second.f[1]; out[2] = it->second.f[2]; }
     return FTN_OK;
 }
-int get_ftex(ftn_pbrt* S, const ParamSet& ps, const char* n, float def, float* out) {
-    auto it = ps.find(n); *out = def;
+int get_ftex(ftn_pbrt* S, const ParamSet& ps, const char* n, float def, float* out, int32_t* tex) {
+    auto it = ps.find(n); *out = def; *tex = -1;
     if (it == ps.end()) return FTN_OK;
-    if (it->second.type == "texture") return fail(S, FTN_ERR_UNSUPPORTED, std::string("non-constant texture for '") + n + "' is outside the hot-path scope");
+    if (it->second.type == "texture") { int i; bool f; int rc = lookup_texture(S, it->second.s[0], &i, &f); if (rc) return rc; if (f) *tex = i; return FTN_OK; }
     if (it->second.type == "float" && !it->second.f.empty()) *out = it->second.f[0];
+    return FTN_OK;
+}
+int new_texture(ftn_pbrt* S, uint32_t kind, bool is_float, const float value[3], int tex1, int tex2, int image, const float map[4]) {
+    ftn_texture t; memset(&t, 0, sizeof(t));
+    t.kind = kind; t.is_float = is_float ? 1u : 0u; t.tex1 = tex1; t.tex2 = tex2; t.image = image;
+    if (value) { t.value[0] = value[0]; t.value[1] = value[1]; t.value[2] = value[2]; }
+    t.su = map ? map[0] : 1.0f; t.sv = map ? map[1] : 1.0f; t.du = map ? map[2] : 0.0f; t.dv = map ? map[3] : 0.0f;
+    S->textures.push_back(t);
+    return (int)S->textures.size() - 1;
+}
+/* get_texture_or_const (loaders/mod.rs:213-225): required; a texture of the other output type is an error */
+int texture_or_const(ftn_pbrt* S, const ParamSet& ps, const char* n, bool is_float, int* out) {
+    auto it = ps.find(n);
+    if (it == ps.end()) return fail(S, FTN_ERR_INVALID_ARGUMENT, std::string("ParamError: missing ") + n);
+    if (it->second.type == "texture") {
+        int i; bool f; int rc = lookup_texture(S, it->second.s[0], &i, &f); if (rc) return rc;
+        if (f != is_float) return fail(S, FTN_ERR_INVALID_ARGUMENT, std::string("ParamError: texture for ") + n + " has the wrong output type");
+        *out = i; return FTN_OK;
+    }
+    float v[3];
+    if (is_float) { if (it->second.type != "float" || it->second.f.empty()) return fail(S, FTN_ERR_INVALID_ARGUMENT, std::string("ParamError: ") + n); v[0] = v[1] = v[2] = it->second.f[0]; }
+    else { if (!is_spectrum(it->second) || it->second.f.size() < 3) return fail(S, FTN_ERR_INVALID_ARGUMENT, std::string("ParamError: ") + n); v[0] = it->second.f[0]; v[1] = it->second.f[1]; v[2] = it->second.f[2]; }
+    *out = new_texture(S, FTN_TEX_CONSTANT, is_float, v, -1, -1, -1, nullptr);
     return FTN_OK;
 }
 
@@ -162,30 +201,79 @@ int load_ply(ftn_pbrt* S, const std::string& path, Mesh* m) {
 
 int add_material(ftn_pbrt* S, const std::string& name, const ParamSet& ps, int* out) {
     ftn_material m; memset(&m, 0, sizeof(m)); m.remap_roughness = 1;
+    ftn_material_textures mt; mt.a = mt.b = mt.s0 = mt.s1 = mt.s2 = -1; mt._pad[0] = mt._pad[1] = mt._pad[2] = 0;
     int rc;
-    const float d05[3] = {0.5f, 0.5f, 0.5f}, d1[3] = {1, 1, 1}, d09[3] = {0.9f, 0.9f, 0.9f}, d025[3] = {0.25f, 0.25f, 0.25f}, d0[3] = {0, 0, 0};
-    if (name == "matte") { m.type = FTN_MAT_MATTE; if ((rc = get_rgb(S, ps, "Kd", d05, m.a)) || (rc = get_ftex(S, ps, "sigma", 0.0f, &m.s0))) return rc; }
+    const float d05[3] = {0.5f, 0.5f, 0.5f}, d1[3] = {1, 1, 1}, d09[3] = {0.9f, 0.9f, 0.9f}, d025[3] = {0.25f, 0.25f, 0.25f};
+    if (name == "matte") { m.type = FTN_MAT_MATTE; if ((rc = get_rgb(S, ps, "Kd", d05, m.a, &mt.a)) || (rc = get_ftex(S, ps, "sigma", 0.0f, &m.s0, &mt.s0))) return rc; }
     else if (name == "glass") {
         m.type = FTN_MAT_GLASS;
-        if ((rc = get_rgb(S, ps, "Kr", d1, m.a)) || (rc = get_rgb(S, ps, "Kt", d1, m.b)) || (rc = get_ftex(S, ps, "uroughness", 0.0f, &m.s1)) || (rc = get_ftex(S, ps, "vroughness", 0.0f, &m.s2)) ||
-            (rc = get_ftex(S, ps, "eta", 1.5f, &m.s0))) return rc;
+        if ((rc = get_rgb(S, ps, "Kr", d1, m.a, &mt.a)) || (rc = get_rgb(S, ps, "Kt", d1, m.b, &mt.b)) || (rc = get_ftex(S, ps, "uroughness", 0.0f, &m.s1, &mt.s1)) ||
+            (rc = get_ftex(S, ps, "vroughness", 0.0f, &m.s2, &mt.s2)) || (rc = get_ftex(S, ps, "eta", 1.5f, &m.s0, &mt.s0))) return rc;
         m.remap_roughness = getb(ps, "remaproughness", true) ? 1 : 0;
-    } else if (name == "mirror") { m.type = FTN_MAT_MIRROR; if ((rc = get_rgb(S, ps, "Kr", d09, m.a))) return rc; }
-    else if (name == "metal") {
+    } else if (name == "mirror") { m.type = FTN_MAT_MIRROR; if ((rc = get_rgb(S, ps, "Kr", d09, m.a, &mt.a))) return rc; }
+    else if (name == "metal") {                                 /* make_metal_material constructors.rs:213-230 */
         m.type = FTN_MAT_METAL;
-        if (ps.find("eta") == ps.end() || ps.find("k") == ps.end()) return fail(S, FTN_ERR_INVALID_ARGUMENT, "metal needs eta and k (constructors.rs:215-216)");
-        if ((rc = get_rgb(S, ps, "eta", d0, m.a)) || (rc = get_rgb(S, ps, "k", d0, m.b))) return rc;
-        float rough; if ((rc = get_ftex(S, ps, "roughness", 0.01f, &rough))) return rc;
-        const bool aniso = ps.find("uroughness") != ps.end() && ps.find("vroughness") != ps.end();
-        if (aniso) { if ((rc = get_ftex(S, ps, "uroughness", 0.0f, &m.s1)) || (rc = get_ftex(S, ps, "vroughness", 0.0f, &m.s2))) return rc; } else { m.s1 = rough; m.s2 = rough; }
+        for (int which = 0; which < 2; which++) {               /* get_texture_or_const: required, spectrum-valued */
+            const char* n = which ? "k" : "eta"; float* dst = which ? m.b : m.a; int32_t* slot = which ? &mt.b : &mt.a;
+            auto it = ps.find(n);
+            if (it == ps.end()) return fail(S, FTN_ERR_INVALID_ARGUMENT, "metal needs eta and k (constructors.rs:215-216)");
+            if (it->second.type == "texture") {
+                int i; bool f; if ((rc = lookup_texture(S, it->second.s[0], &i, &f))) return rc;
+                if (f) return fail(S, FTN_ERR_INVALID_ARGUMENT, std::string("ParamError: texture for ") + n + " has the wrong output type");
+                *slot = i;
+            } else if (is_spectrum(it->second) && it->second.f.size() >= 3) { dst[0] = it->second.f[0]; dst[1] = it->second.f[1]; dst[2] = it->second.f[2]; }
+            else return fail(S, FTN_ERR_INVALID_ARGUMENT, std::string("ParamError: ") + n);
+        }
+        float rough; int32_t trough; if ((rc = get_ftex(S, ps, "roughness", 0.01f, &rough, &trough))) return rc;
+        auto present = [&](const char* n) { auto it = ps.find(n); if (it == ps.end()) return false; if (it->second.type == "float") return true;
+                                            if (it->second.type == "texture") { int i; bool f; return lookup_texture(S, it->second.s[0], &i, &f) == FTN_OK && f; } return false; };
+        if (present("uroughness") && present("vroughness")) { if ((rc = get_ftex(S, ps, "uroughness", 0.0f, &m.s1, &mt.s1)) || (rc = get_ftex(S, ps, "vroughness", 0.0f, &m.s2, &mt.s2))) return rc; }
+        else { m.s1 = rough; m.s2 = rough; mt.s1 = trough; mt.s2 = trough; }
         m.remap_roughness = getb(ps, "remaproughness", true) ? 1 : 0;
     } else if (name == "plastic") {
         m.type = FTN_MAT_PLASTIC;
-        if ((rc = get_rgb(S, ps, "Kd", d025, m.a)) || (rc = get_rgb(S, ps, "ks", d025, m.b)) || (rc = get_ftex(S, ps, "roughness", 0.1f, &m.s1))) return rc;
+        if ((rc = get_rgb(S, ps, "Kd", d025, m.a, &mt.a)) || (rc = get_rgb(S, ps, "ks", d025, m.b, &mt.b)) || (rc = get_ftex(S, ps, "roughness", 0.1f, &m.s1, &mt.s1))) return rc;
         m.remap_roughness = getb(ps, "remaproughness", true) ? 1 : 0;
     } else return fail(S, FTN_ERR_INVALID_ARGUMENT, "UnknownName(" + name + ")");
-    S->materials.push_back(m);
+    S->materials.push_back(m); S->mtex.push_back(mt);
     *out = (int)S->materials.size() - 1;
+    return FTN_OK;
+}
+
+/* PbrtSceneBuilder::texture (pbrt.rs:362-385) + make_checkerboard_* / make_uv_spect / make_imagemap_spect (constructors.rs:247-318) */
+int add_texture(ftn_pbrt* S, const std::string& name, std::string ty, const std::string& cls, const ParamSet& ps) {
+    if (ty == "color") ty = "spectrum";
+    const bool is_float = ty == "float";
+    if (!((ty == "spectrum" && (cls == "checkerboard" || cls == "uv" || cls == "imagemap")) || (is_float && cls == "checkerboard")))
+        return fail(S, FTN_ERR_INVALID_ARGUMENT, "UnknownName(" + ty + " " + cls + ")");
+    { auto it = ps.find("mapping"); if (it != ps.end() && !it->second.s.empty() && it->second.s[0] != "uv") return fail(S, FTN_ERR_INVALID_ARGUMENT, "Unknown mapping type " + it->second.s[0]); }
+    const float map[4] = {getf(ps, "uscale", 1.0f), getf(ps, "vscale", 1.0f), getf(ps, "udelta", 0.0f), getf(ps, "vdelta", 0.0f)};
+    int idx, rc;
+    if (cls == "checkerboard") {
+        int t1, t2;
+        if ((rc = texture_or_const(S, ps, "tex1", is_float, &t1)) || (rc = texture_or_const(S, ps, "tex2", is_float, &t2))) return rc;
+        idx = new_texture(S, FTN_TEX_CHECKERBOARD, is_float, nullptr, t1, t2, -1, map);
+    } else if (cls == "uv") idx = new_texture(S, FTN_TEX_UV, false, nullptr, -1, -1, -1, map);
+    else {
+        auto fn = ps.find("filename");
+        if (fn == ps.end() || fn->second.s.empty()) return fail(S, FTN_ERR_INVALID_ARGUMENT, "ParamError: filename");
+        const std::string file = S->base_dir + "/" + fn->second.s[0];
+        if (file.size() < 4 || file.substr(file.size() - 4) != ".exr") return fail(S, FTN_ERR_UNSUPPORTED, "image maps are read from OpenEXR files only");
+        if (getb(ps, "gamma", false)) return fail(S, FTN_ERR_UNSUPPORTED, "gamma-encoded image maps are not supported (EXR input is linear)");
+        uint32_t wrap = FTN_WRAP_REPEAT;
+        { auto it = ps.find("wrap"); if (it != ps.end() && !it->second.s.empty()) { const std::string& w = it->second.s[0];
+            if (w == "repeat") wrap = FTN_WRAP_REPEAT; else if (w == "black") wrap = FTN_WRAP_BLACK; else if (w == "clamp") wrap = FTN_WRAP_CLAMP; else return fail(S, FTN_ERR_INVALID_ARGUMENT, "Unknown repeat type " + w); } }
+        ftn_pbrt::Img im; im.wrap = wrap;
+        if ((rc = ftn_exr_read(file.c_str(), &im.w, &im.h, nullptr))) return fail(S, rc, ftn_imageio_last_error());
+        im.texels.resize((size_t)im.w * im.h * 3);
+        if ((rc = ftn_exr_read(file.c_str(), &im.w, &im.h, im.texels.data()))) return fail(S, rc, ftn_imageio_last_error());
+        const float scale = getf(ps, "scale", 1.0f);                         /* load_mipmap: texel * scale, then the y flip (imageio/mod.rs:100-117) */
+        for (float& t : im.texels) t = t * scale;
+        for (uint32_t y = 0; y < im.h / 2; y++) for (uint32_t x = 0; x < im.w * 3; x++) std::swap(im.texels[(size_t)y * im.w * 3 + x], im.texels[(size_t)(im.h - 1 - y) * im.w * 3 + x]);
+        S->image_store.push_back(std::move(im));
+        idx = new_texture(S, FTN_TEX_IMAGE, false, nullptr, -1, -1, (int)S->image_store.size() - 1, map);
+    }
+    (is_float ? S->float_textures : S->spectrum_textures)[name] = idx;
     return FTN_OK;
 }
 
@@ -276,13 +364,19 @@ int parse(ftn_pbrt* S, const std::string& path) {
         }
         /* directives of the form  Name "type" params... */
         std::string type;
-        if (w == "Texture") {   /* Texture "name" "type" "class" ... : only constant-per-material inputs are in scope */
-            return fail(S, FTN_ERR_UNSUPPORTED, "Texture statements (image / checkerboard / uv textures) are outside the hot-path scope (SURVEY.md 8(f).2)");
+        if (w == "Texture") {   /* Texture "name" "type" "class" params */
+            std::string names[3];
+            for (int k = 0; k < 3; k++) { if (t.kind != Tok::STR) return fail(S, FTN_ERR_INVALID_ARGUMENT, "Texture: expected name, type and class"); names[k] = t.text; t = L.next(); }
+            ParamSet tps; std::string terr;
+            if (!parse_params(L, t, &tps, &terr)) return fail(S, FTN_ERR_INVALID_ARGUMENT, terr);
+            if ((rc = check_texture_params(S, tps)) || (rc = add_texture(S, names[0], names[1], names[2], tps))) return rc;
+            continue;
         }
         if (t.kind != Tok::STR) return fail(S, FTN_ERR_INVALID_ARGUMENT, w + ": expected a quoted name");
         type = t.text; t = L.next();
         ParamSet ps; std::string perr;
         if (!parse_params(L, t, &ps, &perr)) return fail(S, FTN_ERR_INVALID_ARGUMENT, perr);
+        if (world && (rc = check_texture_params(S, ps))) return rc;
         if (w == "Camera") { S->camera_params = ps; S->camera_params["name"].s = {type}; S->camera_tf = S->header_tf; S->has_camera = true; }
         else if (w == "Sampler") S->sampler_params = ps;
         else if (w == "Film") S->film_params = ps;
@@ -293,26 +387,26 @@ int parse(ftn_pbrt* S, const std::string& path) {
             int m; if ((rc = add_material(S, it->second.s[0], ps, &m))) return rc; S->named_materials[type] = m;
         } else if (w == "AreaLightSource") {
             if (type != "diffuse") return fail(S, FTN_ERR_INVALID_ARGUMENT, "UnknownName(" + type + ")");
-            const float one[3] = {1, 1, 1}; float Lr[3]; if ((rc = get_rgb(S, ps, "L", one, Lr))) return rc;
+            const float one[3] = {1, 1, 1}; float Lr[3]; int32_t nt; if ((rc = get_rgb(S, ps, "L", one, Lr, &nt))) return rc;
             S->area_emit.insert(S->area_emit.end(), Lr, Lr + 3); S->gs.back().area = (int)S->area_emit.size() / 3 - 1;
         } else if (w == "LightSource") {
             ftn_light l; memset(&l, 0, sizeof(l)); l.envmap = -1;
             const float one[3] = {1, 1, 1}, zero[3] = {0, 0, 0}, zup[3] = {0, 0, 1};
             auto vec3 = [&](const char* n, const float def[3], float out[3]) { auto it = ps.find(n); for (int k = 0; k < 3; k++) out[k] = (it != ps.end() && it->second.f.size() >= 3) ? it->second.f[k] : def[k]; };
-            float scale[3]; if ((rc = get_rgb(S, ps, "scale", one, scale))) return rc;
+            float scale[3]; int32_t nt; if ((rc = get_rgb(S, ps, "scale", one, scale, &nt))) return rc;
             if (type == "point") {                                  /* make_point_light constructors.rs:330-337 */
-                float I[3], from[3]; if ((rc = get_rgb(S, ps, "I", one, I))) return rc; vec3("from", zero, from);
+                float I[3], from[3]; if ((rc = get_rgb(S, ps, "I", one, I, &nt))) return rc; vec3("from", zero, from);
                 l.type = FTN_LIGHT_POINT; for (int k = 0; k < 3; k++) l.rgb[k] = I[k] * scale[k];
                 ftn_transform_translate(from, &l.light_to_world); const float o[3] = {0, 0, 0}; ftn_transform_point(&l.light_to_world, o, l.v);
             } else if (type == "distant") {                         /* make_distant_light :320-328, DistantLight::new distant.rs:23-31 */
-                float Lr[3], from[3], to[3]; if ((rc = get_rgb(S, ps, "L", one, Lr))) return rc; vec3("from", zero, from); vec3("to", zup, to);
+                float Lr[3], from[3], to[3]; if ((rc = get_rgb(S, ps, "L", one, Lr, &nt))) return rc; vec3("from", zero, from); vec3("to", zup, to);
                 l.type = FTN_LIGHT_DISTANT; for (int k = 0; k < 3; k++) l.rgb[k] = Lr[k] * scale[k];
                 const float d[3] = {from[0] - to[0], from[1] - to[1], from[2] - to[2]};
                 const float mag = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), inv = 1.0f / mag;
                 for (int k = 0; k < 3; k++) l.v[k] = d[k] * inv;
                 ftn_transform_identity(&l.light_to_world);
             } else if (type == "infinite") {                        /* make_infinite_area_light :339-359 */
-                float Lr[3]; if ((rc = get_rgb(S, ps, "L", one, Lr))) return rc;
+                float Lr[3]; if ((rc = get_rgb(S, ps, "L", one, Lr, &nt))) return rc;
                 l.type = FTN_LIGHT_INFINITE; l.light_to_world = S->tf.back();
                 ftn_pbrt::Env env;
                 auto mn = ps.find("mapname");
@@ -385,6 +479,11 @@ int parse(ftn_pbrt* S, const std::string& path) {
     d.n_area_emit = (uint32_t)(S->area_emit.size() / 3); d.area_emit = S->area_emit.data();
     d.n_lights = (uint32_t)S->lights.size(); d.lights = S->lights.data();
     d.n_envmaps = (uint32_t)S->envmaps.size(); d.envmaps = S->envmaps.data();
+    if (!S->textures.empty()) {
+        for (auto& im : S->image_store) { ftn_image i; i.width = im.w; i.height = im.h; i.wrap = im.wrap; i._pad = 0; i.texels = im.texels.data(); S->images.push_back(i); }
+        d.n_textures = (uint32_t)S->textures.size(); d.textures = S->textures.data(); d.material_textures = S->mtex.data();
+        d.n_images = (uint32_t)S->images.size(); d.images = S->images.data();
+    }
     return FTN_OK;
 }
 

@@ -20,6 +20,7 @@
  * pipelines produce identical radiance.  Dominant kernel: k_wf_trace<false>; roofline = HBM (node + triangle fetches).
  */
 #include "ftn_wavefront.h"
+#include "ftn_texture.h"
 #include <string>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
@@ -518,6 +519,7 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 #ifndef FTN_SHADE_MIN_WAVES
 #define FTN_SHADE_MIN_WAVES 1
 #endif
+template <bool TEX>
 __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
     const DScene& S = P.S;
     /* virtual, 256-aligned concatenation of the class segments: a workgroup never straddles two classes */
@@ -602,7 +604,22 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                         push_closest = true;
                     } else {
                         DBsdf B;
-                        if (!make_bsdf(S.materials[mat], si, true, &B)) { err = FTN_ERR_UNSUPPORTED; alive = false; }
+                        ftn_material mloc; const ftn_material* mp = &S.materials[mat];
+                        if (TEX && material_is_textured(S, mat)) {
+                            /* Texture::evaluate(si).  The differentials are the CAMERA ray's, handed on unchanged by the path integrator
+                             * (path.rs:73): rebuilt here from the path's sample key instead of being carried in the path state. */
+                            const uint32_t slot = p % W.n_slots, sidx = p / W.n_slots;
+                            const DTile tile = P.tiles[slot >> 8];
+                            const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
+                            Rng crng; crng.seed(indexed_key(P.seed, px, py, W.first_sample + sidx));
+                            const V2 j = crng.next2(); const V2 p_film((float)px + j.x, (float)py + j.y); const V2 p_lens = crng.next2(); const float time_u = crng.next();
+                            const DRay cam = camera_ray(P.C, p_film, p_lens, time_u);
+                            const DRayDiff rd = camera_ray_diff(P.C, p_film, p_lens, cam, 1.0f / sqrtf((float)P.spp));
+                            DSIX ex; DSI s2; make_interaction(S, h, ray0, &s2, &ex);
+                            const DTexDiffs td = compute_tex_diffs(si.hit.p, si.hit.n, ex.dpdu, ex.dpdv, rd);
+                            mloc = material_resolve(S, mat, ex.uv, td); mp = &mloc;
+                        }
+                        if (!make_bsdf(*mp, si, true, &B)) { err = FTN_ERR_UNSUPPORTED; alive = false; }
                         else {
                             if (bsdf_num(B, T_ALL & ~T_SPECULAR) > 0 && S.n_lights > 0) {
                                 /* uniform_sample_one_light + first half of estimate_direct (integrator/mod.rs:289-329) */
@@ -903,7 +920,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
             }
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
-            hipLaunchKernelGGL(k_wf_shade, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
+            if (P.S.n_textures != 0) hipLaunchKernelGGL(k_wf_shade<true>, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
+            else hipLaunchKernelGGL(k_wf_shade<false>, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
             in_q ^= 1;
             if (const uint32_t sort_mode = knob("FTN_WF_SORT", 0)) {   /* experiment: reorder the two ray queues for the next traces */
                 const uint32_t bits = knob("FTN_WF_SORT_BITS", 7);

@@ -143,6 +143,37 @@ typedef struct ftn_envmap {
     const float* texels;
 } ftn_envmap;
 
+/* Textures (the files under src/texture/) as a flat array; a material parameter is either the constant stored in ftn_material or, through
+ * ftn_material_textures, the index of a texture evaluated at every hit (Texture::evaluate(si), texture/mod.rs:12-16).
+ * CONSTANT  ConstantTexture                    value
+ * UV        UVTexture            uv.rs:17-23   (s - floor s, t - floor t, 0) of the mapped coordinates
+ * CHECKER   Checkerboard2DTexture checkerboard.rs:49-64 (AAMethod::None): tex1 if (floor s + floor t) % 2 == 0 else tex2
+ * IMAGE     ImageTexture         image.rs:28-34 -> MIPMap::lookup_trilinear(st, dst/dx, dst/dy), mipmap.rs:273-306
+ * Every non-constant texture carries its UVMapping (mapping.rs:12-53): st = (su*u + du, sv*v + dv).                          */
+enum { FTN_TEX_CONSTANT = 0, FTN_TEX_UV = 1, FTN_TEX_CHECKERBOARD = 2, FTN_TEX_IMAGE = 3 };
+enum { FTN_WRAP_REPEAT = 0, FTN_WRAP_BLACK = 1, FTN_WRAP_CLAMP = 2 };     /* ImageWrap, mipmap.rs:14-17 */
+typedef struct ftn_texture {
+    uint32_t kind;        /* FTN_TEX_*                                                  */
+    uint32_t is_float;    /* 1: Texture<Output = Float> (value[0]); 0: Spectrum          */
+    float value[3];       /* CONSTANT                                                   */
+    int32_t tex1, tex2;   /* CHECKERBOARD: indices into textures (same output type)      */
+    int32_t image;        /* IMAGE: index into images                                    */
+    float su, sv, du, dv; /* UVMapping{scale_u, scale_v, offset_u, offset_v}             */
+} ftn_texture;
+/* The texels handed to MIPMap::new by load_mipmap (imageio/mod.rs:81-124: after scale, inverse gamma and the y flip), RGB,
+ * texels[(t*width + s)*3 + c]; ftn_scene_create builds the pyramid (mipmap.rs:78-145).  Any size (no power-of-two rule here). */
+typedef struct ftn_image {
+    uint32_t width, height;
+    uint32_t wrap;        /* FTN_WRAP_*                                                  */
+    uint32_t _pad;
+    const float* texels;
+} ftn_image;
+/* Per material (same index as materials[]): texture index for each parameter slot of ftn_material, -1 = use the constant. */
+typedef struct ftn_material_textures {
+    int32_t a, b, s0, s1, s2;
+    int32_t _pad[3];
+} ftn_material_textures;
+
 typedef struct ftn_scene_desc {
     uint32_t n_prims;      const ftn_prim* prims;
     uint32_t n_triangles;  const uint32_t* tri_indices;  /* 3 per triangle, into the vertex pool */
@@ -156,6 +187,10 @@ typedef struct ftn_scene_desc {
     uint32_t n_area_emit;  const float* area_emit;       /* 3 per entry (DiffuseAreaLight emit)   */
     uint32_t n_lights;     const ftn_light* lights;
     uint32_t n_envmaps;    const ftn_envmap* envmaps;
+    /* optional (zero / NULL when every material parameter is constant) */
+    uint32_t n_textures;   const ftn_texture* textures;
+                           const ftn_material_textures* material_textures;   /* n_materials entries or NULL */
+    uint32_t n_images;     const ftn_image* images;
 } ftn_scene_desc;
 
 /* ------------------------------------------------------------------ camera / film / sampler / integrator */
@@ -375,6 +410,11 @@ const char* ftn_imageio_last_error(void);
  * with a CPU evaluation): which = 0 sin, 1 cos, 2 tan, 3 acos, 4 atan, 5 atan2(x,y), 6 ln, 7 log2, 8 sqrt, 9 x/y,
  * 10 (float)sqrt((double)x * y)  [the f64 path of math.rs:37-42], 11 next_float_up, 12 next_float_down.                 */
 int ftn_test_math(int which, const float* x, const float* y, size_t n, float* out);
+/* Texture path hooks.  ftn_test_mipmap_level (host only): level `level` of the pyramid MIPMap::new builds for an image (mipmap.rs:78-145);
+ * pass rgb_out = NULL for the size.  ftn_test_texture_eval: Texture::evaluate ON THE DEVICE for n rows of
+ * {u, v, dudx, dvdx, dudy, dvdy} (HOST memory) -> rgb_out[3n] (a float texture repeats its value).                              */
+int ftn_test_mipmap_level(uint32_t width, uint32_t height, const float* texels, uint32_t level, uint32_t* level_w, uint32_t* level_h, float* rgb_out);
+int ftn_test_texture_eval(const ftn_scene* scene, int32_t texture, const float* uv_diffs6, size_t n, float* rgb_out);
 
 /* ------------------------------------------------------------------ misc */
 const char* ftn_last_error(void);

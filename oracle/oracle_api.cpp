@@ -276,5 +276,34 @@ float orc_kat_math(int which, float x, float y) {
                      case 4: return m_atan(x); case 5: return m_atan2(x, y); case 6: return m_ln(x); case 7: return m_log2(x); default: return 0.0f; }
 }
 float orc_kat_roughness_to_alpha(float r) { return roughness_to_alpha(r); }
+// ---- textures (orc_texture.hpp)
+// a level of the pyramid MIPMap::new builds (mipmap.rs:78-145)
+int orc_test_mipmap_level(uint32_t w, uint32_t h, const float* texels, uint32_t level, uint32_t* lw, uint32_t* lh, float* rgb_out) {
+    MIPMap m = MIPMap::make((int)w, (int)h, texels, FTN_WRAP_REPEAT);
+    if ((int)level >= m.levels()) return FTN_ERR_INVALID_ARGUMENT;
+    const MipLevel& L = m.pyramid[level];
+    if (lw) *lw = (uint32_t)L.w;
+    if (lh) *lh = (uint32_t)L.h;
+    if (rgb_out) for (size_t i = 0; i < L.data.size(); i++) for (int c = 0; c < 3; c++) rgb_out[3 * i + c] = L.data[i][c];
+    return FTN_OK;
+}
+// Texture::evaluate for rows of {u, v, dudx, dvdx, dudy, dvdy}
+int orc_test_texture_eval(const orc_scene* s, int32_t texture, const float* in6, size_t n, float* out3) {
+    if (texture < 0 || (size_t)texture >= s->data.tex.textures.size()) return FTN_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; i++) {
+        SurfaceInteraction si; si.uv = Vec2(in6[6 * i], in6[6 * i + 1]);
+        si.tex_diffs.dudx = in6[6 * i + 2]; si.tex_diffs.dvdx = in6[6 * i + 3]; si.tex_diffs.dudy = in6[6 * i + 4]; si.tex_diffs.dvdy = in6[6 * i + 5];
+        Spectrum c = s->data.tex.evaluate(texture, si);
+        out3[3 * i] = c[0]; out3[3 * i + 1] = c[1]; out3[3 * i + 2] = c[2];
+    }
+    return FTN_OK;
+}
+// MIPMap::lookup_trilinear_width on an image built by MIPMap::new (custom = 0) or new_custom (custom = 1): rows of {s, t, width}
+void orc_kat_mipmap_lookup(uint32_t w, uint32_t h, const float* texels, int wrap, int custom, const float* st_width3, size_t n, float* out3) {
+    MIPMap m;
+    if (custom) { std::vector<Spectrum> img((size_t)w * h); for (size_t i = 0; i < img.size(); i++) img[i] = Spectrum(texels[3 * i], texels[3 * i + 1], texels[3 * i + 2]); m = MIPMap::make_custom((int)w, (int)h, img, wrap); }
+    else m = MIPMap::make((int)w, (int)h, texels, wrap);
+    for (size_t i = 0; i < n; i++) { Spectrum c = m.lookup_trilinear_width(Vec2(st_width3[3 * i], st_width3[3 * i + 1]), st_width3[3 * i + 2]); out3[3 * i] = c[0]; out3[3 * i + 1] = c[1]; out3[3 * i + 2] = c[2]; }
+}
 
 }  // extern "C"

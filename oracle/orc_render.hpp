@@ -276,7 +276,8 @@ inline int scattering_functions(SurfaceInteraction& si, const RayDifferential& r
     si.compute_tex_differentials(ray);
     int mat = scene.bvh.prims[si.prim].material;
     if (mat < 0) return 0;
-    if (compute_scattering_functions(scene.materials[mat], si, allow_multiple_lobes, bsdf) != MAT_OK) { scene.error.store(FTN_ERR_UNSUPPORTED); return -1; }
+    const ftn_material resolved = scene.tex.resolve(scene.materials[mat], scene.mtex.empty() ? nullptr : &scene.mtex[mat], si);   // Texture::evaluate(si)
+    if (compute_scattering_functions(resolved, si, allow_multiple_lobes, bsdf) != MAT_OK) { scene.error.store(FTN_ERR_UNSUPPORTED); return -1; }
     return 1;
 }
 
@@ -330,9 +331,31 @@ inline Spectrum specular_bounce_li(const Integrator& it, const RayDifferential& 
     Vec2 u = sampler.get_2d();                                              // evaluated before the match, mod.rs:52 / :113
     if (!bsdf.sample_f(wo, u, flags, &sc)) return Spectrum(0.0f);
     if (abs_dot(sc.wi, isect.shading_n) == 0.0f) return Spectrum(0.0f);
-    // The differential update (mod.rs:58-84 / :119-163) only feeds texture filtering; all textures are constant,
-    // so the child ray keeps no differentials here.
-    RayDifferential child; child.ray = isect.hit.spawn_ray(sc.wi); child.has_diff = false; (void)ray;
+    RayDifferential child; child.ray = isect.hit.spawn_ray(sc.wi); child.has_diff = ray.has_diff;
+    if (ray.has_diff) {                                                     // ray.diff.map(..): mod.rs:58-84 (reflect) / :119-163 (transmit)
+        const TextureDifferentials& td = isect.tex_diffs; const DiffGeom& sh = isect.shading_geom; const Differential& diff = ray.diff;
+        Differential o;
+        o.rx_origin = isect.hit.p + td.dpdx; o.ry_origin = isect.hit.p + td.dpdy;
+        Vec3 dndx = sh.dndu * td.dudx + sh.dndv * td.dvdx, dndy = sh.dndu * td.dudy + sh.dndv * td.dvdy;
+        Vec3 ns = isect.shading_n;
+        if (flags & BSDF_REFLECTION) {
+            Vec3 dwo_dx = -diff.rx_dir - wo, dwo_dy = -diff.ry_dir - wo;
+            Float dDN_dx = dot(dwo_dx, ns) + dot(wo, dndx), dDN_dy = dot(dwo_dy, ns) + dot(wo, dndy);
+            o.rx_dir = (sc.wi - dwo_dx) + (2.0f * dot(wo, ns)) * dndx + dDN_dx * ns;
+            o.ry_dir = (sc.wi - dwo_dy) + (2.0f * dot(wo, ns)) * dndy + dDN_dy * ns;
+        } else {
+            Vec3 sn = ns; Float eta = 1.0f / bsdf.eta;
+            if (dot(wo, ns) < 0.0f) { eta = bsdf.eta; sn = -sn; dndx = -dndx; dndy = -dndy; }
+            Vec3 dwo_dx = -diff.rx_dir - wo, dwo_dy = -diff.ry_dir - wo;
+            Float dDN_dx = dot(dwo_dx, ns) + dot(wo, dndx), dDN_dy = dot(dwo_dy, ns) + dot(wo, dndy);   // unflipped normal, flipped dndx (:142-143)
+            Float mu = eta * dot(wo, sn) - abs_dot(sc.wi, sn);
+            Float dmu_dx = (eta - (eta * eta * dot(wo, sn)) / dot(sc.wi, sn)) * dDN_dx;
+            Float dmu_dy = (eta - (eta * eta * dot(wo, sn)) / dot(sc.wi, sn)) * dDN_dy;
+            o.rx_dir = sc.wi - (eta * dwo_dx) + (mu * dndx + dmu_dx * sn);
+            o.ry_dir = sc.wi - (eta * dwo_dy) + (mu * dndy + dmu_dy * sn);
+        }
+        child.diff = o;
+    }
     Spectrum li = direct_li(it, child, scene, sampler, depth + 1);
     return sc.f * li * fabsf(dot(sc.wi, isect.shading_n)) / sc.pdf;
 }

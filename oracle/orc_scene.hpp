@@ -3,6 +3,7 @@
 // (Distribution1D/2D), level-0 bilinear lookup of src/mipmap.rs.
 #pragma once
 #include "orc_reflection.hpp"
+#include "orc_texture.hpp"
 #include <memory>
 #include <deque>
 #include <atomic>
@@ -336,6 +337,7 @@ struct SceneData {
     std::vector<Triangle> triangles;
     std::vector<Sphere> spheres;
     std::vector<ftn_material> materials;
+    TextureSet tex; std::vector<ftn_material_textures> mtex;    // empty mtex: every parameter constant
     std::vector<EnvMap> envmaps;
     std::vector<Light> lights;
     BVH bvh;
@@ -402,6 +404,7 @@ inline int build_scene(const ftn_scene_desc* d, SceneData* s) {
         sp.radius = q.radius; sp.z_min = q.z_min; sp.z_max = q.z_max; sp.theta_min = q.theta_min; sp.theta_max = q.theta_max; sp.phi_max = q.phi_max;
     }
     s->materials.assign(d->materials, d->materials + d->n_materials);
+    { int trc = build_textures(d, &s->tex, &s->mtex); if (trc) return trc; }
     s->envmaps.resize(d->n_envmaps);
     for (uint32_t i = 0; i < d->n_envmaps; i++) {
         EnvMap& e = s->envmaps[i]; e.w = (int)d->envmaps[i].width; e.h = (int)d->envmaps[i].height;

@@ -34,7 +34,10 @@ def desc_arrays(d):
         "materials": _arr(d.materials, d.n_materials * 11, np.uint32).reshape(-1, 11) if d.n_materials else np.zeros((0, 11), np.uint32),
         "area_emit": _arr(d.area_emit, d.n_area_emit * 3, np.uint32),
         "lights": _arr(d.lights, d.n_lights * 40, np.uint32),
+        "textures": _arr(d.textures, d.n_textures * 12, np.uint32),
+        "material_textures": _arr(d.material_textures, d.n_materials * 8, np.int32).reshape(-1, 8)[:, :5] if d.material_textures else None,
     }
+    out["images"] = [(im.width, im.height, im.wrap, _arr(im.texels, im.width * im.height * 3, np.uint32)) for im in (d.images[i] for i in range(d.n_images))]
     # material _pad is not meaningful: compare the 11 leading words only (done by the reshape above: 48 B = 12 words)
     out["materials"] = _arr(d.materials, d.n_materials * 12, np.uint32).reshape(-1, 12)[:, :11]
     envs = []
@@ -48,10 +51,10 @@ def desc_arrays(d):
 def assert_same_desc(a, b):
     da, db = desc_arrays(a), desc_arrays(b)
     for k in da:
-        if k == "envmaps":
+        if k in ("envmaps", "images"):
             assert len(da[k]) == len(db[k])
             for x, y in zip(da[k], db[k]):
-                assert x[0] == y[0] and x[1] == y[1] and np.array_equal(x[2], y[2])
+                assert x[:-1] == y[:-1] and np.array_equal(x[-1], y[-1])
         elif da[k] is None or db[k] is None:
             assert da[k] is None and db[k] is None, k
         else:
@@ -223,8 +226,11 @@ def test_every_supported_statement(ftn, tmp_path):
 
 @pytest.mark.parametrize("body,code", [
     ('ObjectBegin "a"', A.FTN_ERR_UNSUPPORTED),                                             # unimplemented!() pbrt.rs:196
-    ('Texture "t" "spectrum" "checkerboard"', A.FTN_ERR_UNSUPPORTED),                      # non-constant textures: 8(f).2
-    ('Material "matte" "texture Kd" "t"', A.FTN_ERR_UNSUPPORTED),
+    ('Texture "t" "spectrum" "checkerboard"', A.FTN_ERR_INVALID_ARGUMENT),                 # tex1 / tex2 are required (constructors.rs:265-266)
+    ('Texture "t" "float" "uv"', A.FTN_ERR_INVALID_ARGUMENT),                              # UnknownName("float uv") pbrt.rs:381
+    ('Texture "t" "spectrum" "uv" "string mapping" "spherical"', A.FTN_ERR_INVALID_ARGUMENT),
+    ('Material "matte" "texture Kd" "t"', A.FTN_ERR_INVALID_ARGUMENT),                     # TextureError: lookup_texture pbrt.rs:142-147
+    ('Texture "t" "spectrum" "imagemap" "string filename" "x.png"', A.FTN_ERR_UNSUPPORTED),
     ('Material "velvet"', A.FTN_ERR_INVALID_ARGUMENT),                                      # UnknownName
     ('NamedMaterial "nope"', A.FTN_ERR_INVALID_ARGUMENT),                                   # MaterialError
     ('Shape "cone"', A.FTN_ERR_INVALID_ARGUMENT),
@@ -247,3 +253,55 @@ def test_plastic_reads_lowercase_ks(ftn, tmp_path):
     ps = PbrtScene(str(p), ftn)
     m = ps.desc.materials[ps.desc.prims[0].material]
     assert m.type == A.FTN_MAT_PLASTIC and list(m.b) == [0.25, 0.25, 0.25]
+
+
+TEXTURED = """
+Camera "perspective"
+WorldBegin
+Texture "chk" "spectrum" "checkerboard" "float uscale" 8 "float vscale" 4 "rgb tex1" [0.1 0.2 0.3] "rgb tex2" [0.8 0.7 0.6]
+Texture "fchk" "float" "checkerboard" "float tex1" 0 "float tex2" 30 "float udelta" 0.5
+Texture "grid" "color" "uv" "float uscale" 2 "float vdelta" 0.25
+Texture "img" "spectrum" "imagemap" "string filename" "t.exr" "string wrap" "clamp" "float scale" 0.5
+Texture "nest" "spectrum" "checkerboard" "texture tex1" "grid" "texture tex2" "img"
+Material "matte" "texture Kd" "chk" "texture sigma" "fchk"
+Shape "sphere"
+Material "matte" "texture Kd" "fchk"
+Shape "sphere" "float radius" 2
+Material "plastic" "texture Kd" "nest" "texture ks" "grid" "texture roughness" "fchk"
+Shape "sphere" "float radius" 3
+Material "metal" "texture eta" "img" "rgb k" [3 2 1] "texture roughness" "fchk"
+Shape "sphere" "float radius" 4
+Material "mirror" "texture Kr" "chk"
+Shape "sphere" "float radius" 5
+Material "glass" "texture Kr" "grid" "texture Kt" "chk" "texture uroughness" "fchk" "float vroughness" 0.2
+Shape "sphere" "float radius" 6
+WorldEnd
+"""
+
+
+def test_texture_statements(ftn, tmp_path):
+    """Texture statements and "texture" parameters (pbrt.rs:362-385, constructors.rs:247-318) against SceneBuilder.texture()."""
+    from fountain_amd import write_exr
+    rng = np.random.default_rng(4)
+    img = rng.random((6, 10, 3)).astype(np.float32)              # not a power of two: MIPMap::new takes any size
+    write_exr(str(tmp_path / "t.exr"), img, ftn)
+    (tmp_path / "s.pbrt").write_text(TEXTURED)
+    ps = PbrtScene(str(tmp_path / "s.pbrt"), ftn)
+    b = SceneBuilder(ftn)
+    b.texture("chk", "spectrum", "checkerboard", uscale=8.0, vscale=4.0, tex1=(0.1, 0.2, 0.3), tex2=(0.8, 0.7, 0.6))
+    b.texture("fchk", "float", "checkerboard", tex1=0.0, tex2=30.0, udelta=0.5)
+    b.texture("grid", "color", "uv", uscale=2.0, vdelta=0.25)
+    b.texture("img", "spectrum", "imagemap", texels=img, wrap="clamp", scale=0.5)
+    b.texture("nest", "spectrum", "checkerboard", tex1="grid", tex2="img")
+    b.material("matte", Kd="chk", sigma="fchk"); b.shape("sphere")
+    b.material("matte", Kd="fchk"); b.shape("sphere", radius=2.0)             # float texture in a spectrum slot -> the default 0.5
+    b.material("plastic", Kd="nest", Ks="grid", roughness="fchk"); b.shape("sphere", radius=3.0)
+    b.material("metal", eta="img", k=(3, 2, 1), roughness="fchk"); b.shape("sphere", radius=4.0)
+    b.material("mirror", Kr="chk"); b.shape("sphere", radius=5.0)
+    b.material("glass", Kr="grid", Kt="chk", uroughness="fchk", vroughness=0.2); b.shape("sphere", radius=6.0)
+    d, keep = b.build_desc()
+    assert_same_desc(ps.desc, d)
+    assert d.n_textures == 9 and d.n_images == 1 and list(d.materials[2].a) == [0.5, 0.5, 0.5] and d.material_textures[2].a == -1
+    # the stored image is the file flipped in y and scaled (load_mipmap, imageio/mod.rs:100-117)
+    got = np.frombuffer(C.string_at(C.cast(ps.desc.images[0].texels, C.c_void_p), 6 * 10 * 3 * 4), np.float32).reshape(6, 10, 3)
+    assert np.array_equal(got, (img * np.float32(0.5))[::-1])

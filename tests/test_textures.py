@@ -1,0 +1,235 @@
+"""Surface textures, the MIP pyramid and ray differentials.
+
+CPU part: the oracle against the reference's own mipmap test (mipmap.rs:370-388) and against closed forms; the product's host-side
+pyramid builder against the oracle's.  GPU part: Texture::evaluate on the device and textured renders (path in both pipelines,
+direct lighting and Whitted with differentials followed through a mirror) bit-exact against the deterministic-math oracle.
+
+Pyramid levels >= 1 come from the un-vendored `resize` crate in the reference: both sides restate its published algorithm, the
+claim against the crate itself is "parity unpinned" (oracle/orc_texture.hpp header)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fountain_amd import (DirectLightingIntegrator, PathIntegrator, PerspectiveCamera, RandomSampler, SceneBuilder, WhittedIntegrator,
+                          _abi as A, scenes)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def mip_level(be, img, level):
+    h, w = img.shape[:2]
+    fn = be.lib.orc_test_mipmap_level if be.is_oracle else be.lib.ftn_test_mipmap_level
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lw, lh = C.c_uint32(), C.c_uint32()
+    img = np.ascontiguousarray(img, np.float32)
+    if fn(w, h, _fp(img), level, C.cast(C.byref(lw), C.c_void_p), C.cast(C.byref(lh), C.c_void_p), None) != 0:
+        return None
+    out = np.empty((lh.value, lw.value, 3), np.float32)
+    assert fn(w, h, _fp(img), level, None, None, _fp(out)) == 0
+    return out
+
+
+def tex_eval(scene, tex, rows):
+    rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 6)
+    out = np.empty((rows.shape[0], 3), np.float32)
+    be = scene.be
+    fn = be.lib.orc_test_texture_eval if be.is_oracle else be.lib.ftn_test_texture_eval
+    fn.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+    assert fn(scene.handle, tex, _fp(rows), rows.shape[0], _fp(out)) == 0
+    return out
+
+
+def ulps(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+# ------------------------------------------------------------------ CPU: oracle KATs and closed forms
+@pytest.mark.parametrize("custom,dims", [(1, (16, 15)), (0, (16, 16)), (0, (20, 10))])
+def test_reference_mipmap_lookup(orc, custom, dims):
+    """mipmap.rs:370-388 (test_mipmap_lookup, new_custom on 16x15) and the same property for MIPMap::new (the test_mipmap_creation
+    sizes): a constant 0.5 image reads back 0.5 within 6 ulps at every coordinate and filter width."""
+    w, h = dims
+    img = np.full((h, w, 3), 0.5, np.float32)
+    widths = list(np.logspace(-4.0, 0.0, 10)) + [0.0]
+    coords = np.linspace(0.0, 1.0, 25)
+    rows = np.array([(s, t, wd) for s in coords for t in coords for wd in widths], np.float32)
+    out = np.empty((rows.shape[0], 3), np.float32)
+    fn = orc.lib.orc_kat_mipmap_lookup
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    fn.restype = None
+    fn(w, h, _fp(img), A.FTN_WRAP_REPEAT, custom, _fp(rows), rows.shape[0], _fp(out))
+    assert ulps(out, np.float32(0.5)).max() <= 6
+
+
+def test_pyramid_levels_have_the_reference_shape_and_box_like_weights(orc):
+    rng = np.random.default_rng(3)
+    img = rng.random((8, 16, 3)).astype(np.float32)
+    shapes = [mip_level(orc, img, l).shape[:2] for l in range(5)]
+    assert shapes == [(8, 16), (4, 8), (2, 4), (1, 2), (1, 1)] and mip_level(orc, img, 5) is None     # 1 + log2(max(w, h)) levels
+    # 2:1 Triangle: interior taps 1/8 3/8 3/8 1/8 in each direction (resize: support scaled by the ratio, normalised)
+    l1 = mip_level(orc, img, 1)
+    wts = np.array([0.125, 0.375, 0.375, 0.125])
+    want = np.einsum("a,b,abc->c", wts, wts, img[1:5, 1:5].astype(np.float64))                         # output texel (1, 1)
+    assert np.allclose(l1[1, 1], want, rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (6, 10), (7, 1), (17, 33), (64, 32)])
+def test_host_pyramid_matches_oracle(ftn, orc, shape):
+    """the product's pyramid builder (host code of ftn_scene_create) against the oracle's, every level, bit for bit"""
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = (rng.random(shape + (3,)) * 4).astype(np.float32)
+    level = 0
+    while True:
+        a, b = mip_level(ftn, img, level), mip_level(orc, img, level)
+        assert (a is None) == (b is None)
+        if a is None:
+            break
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), level
+        level += 1
+    assert level == 1 + int(np.floor(np.log2(max(shape))))
+
+
+def texture_zoo(be, img):
+    """one scene holding every texture kind; returns (builder, {name: texture index})"""
+    b = SceneBuilder(be)
+    ids = {}
+    ids["chk"] = b.texture("chk", "spectrum", "checkerboard", uscale=8.0, vscale=4.0, tex1=(0.1, 0.2, 0.3), tex2=(0.8, 0.7, 0.6))
+    ids["fchk"] = b.texture("fchk", "float", "checkerboard", tex1=0.0, tex2=30.0, udelta=0.5)
+    ids["grid"] = b.texture("grid", "color", "uv", uscale=2.0, vdelta=0.25)
+    for wrap in ("repeat", "black", "clamp"):
+        ids["img_" + wrap] = b.texture("img_" + wrap, "spectrum", "imagemap", texels=img, wrap=wrap, scale=0.5, uscale=1.5, vdelta=-0.1)
+    ids["nest"] = b.texture("nest", "spectrum", "checkerboard", tex1="grid", tex2="img_repeat", uscale=3.0, vscale=3.0)
+    b.material("matte", Kd="nest")
+    b.shape("sphere")
+    return b, ids
+
+
+def test_texture_evaluate_closed_forms(orc):
+    rng = np.random.default_rng(8)
+    img = rng.random((6, 10, 3)).astype(np.float32)
+    b, ids = texture_zoo(orc, img)
+    sc = b.create_scene()
+    uv = (rng.random((4000, 2)) * 6 - 2).astype(np.float32)
+    rows = np.concatenate([uv, np.zeros((4000, 4), np.float32)], axis=1)
+    # checkerboard.rs:49-64
+    s, t = np.float32(8.0) * uv[:, 0], np.float32(4.0) * uv[:, 1]
+    even = ((np.floor(s).astype(np.int64) + np.floor(t).astype(np.int64)) % 2) == 0
+    got = tex_eval(sc, ids["chk"], rows)
+    assert np.array_equal(got, np.where(even[:, None], np.float32([0.1, 0.2, 0.3]), np.float32([0.8, 0.7, 0.6])))
+    # uv.rs:17-23
+    s, t = np.float32(2.0) * uv[:, 0], uv[:, 1] + np.float32(0.25)
+    got = tex_eval(sc, ids["grid"], rows)
+    assert np.array_equal(got, np.stack([s - np.floor(s), t - np.floor(t), np.zeros_like(s)], axis=1))
+    # a float checkerboard repeats its value; udelta shifts it
+    got = tex_eval(sc, ids["fchk"], rows)
+    even = ((np.floor(uv[:, 0] + np.float32(0.5)).astype(np.int64) + np.floor(uv[:, 1]).astype(np.int64)) % 2) == 0
+    assert np.array_equal(got[:, 0], np.where(even, np.float32(0.0), np.float32(30.0))) and np.array_equal(got[:, 0], got[:, 2])
+    # image.rs + mipmap.rs:294-306 at zero footprint: bilinear in level 0 of the y-flipped, scaled image, wrap = repeat
+    lvl0 = (img * np.float32(0.5))[::-1].astype(np.float64)
+    s, t = (np.float32(1.5) * uv[:, 0]).astype(np.float64), (uv[:, 1] + np.float32(-0.1)).astype(np.float64)
+    x, y = s * 10 - 0.5, t * 6 - 0.5
+    x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+    dx, dy = (x - x0)[:, None], (y - y0)[:, None]
+    tx = lambda xx, yy: lvl0[yy % 6, xx % 10]
+    want = tx(x0, y0) * (1 - dx) * (1 - dy) + tx(x0, y0 + 1) * (1 - dx) * dy + tx(x0 + 1, y0) * dx * (1 - dy) + tx(x0 + 1, y0 + 1) * dx * dy
+    got = tex_eval(sc, ids["img_repeat"], rows)
+    assert np.allclose(got, want, rtol=0, atol=2e-5)          # f32 products near texel edges (|s| up to 6*1.5)
+    # a footprint as wide as the whole image returns the coarsest level's single texel (mipmap.rs:277-279)
+    wide = rows.copy(); wide[:, 2] = 1.0
+    got = tex_eval(sc, ids["img_clamp"], wide)
+    assert np.all(got == got[0]) and np.allclose(got[0], lvl0.mean(axis=(0, 1)), rtol=0.2)
+
+
+def _textured_quad(be, integ_light="distant"):
+    b = SceneBuilder(be)
+    b.texture("grid", "spectrum", "uv")
+    b.material("matte", Kd="grid")
+    b.shape("trianglemesh", P=[(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], uv=[0, 0, 1, 0, 1, 1, 0, 1], indices=[0, 1, 2, 0, 2, 3])
+    b.light_source("distant", L=(np.pi, np.pi, np.pi), from_=(0, 0, 1), to=(0, 0, 0))
+    cam = PerspectiveCamera.look_at(be, (0, 0, 5), (0, 0, 0), (0, 1, 0), (32, 32), fov=2 * np.degrees(np.arctan(1 / 5.0)))
+    return b, cam, (32, 32)
+
+
+@pytest.mark.parametrize("integ", [WhittedIntegrator(2), DirectLightingIntegrator(2), PathIntegrator.new(1, 1.0)])
+def test_uv_textured_quad_shows_its_uvs(orc, integ):
+    """a matte quad whose Kd is the UV texture under a head-on distant light of radiance pi: L = Kd/pi * pi * 1 = (u, v, 0)"""
+    b, cam, res = _textured_quad(orc)
+    rgb = scenes.render(orc, b, cam, res, integ, RandomSampler(16, 0))[0]
+    u = (np.arange(32) + 0.5) / 32
+    # image x runs along +x (u), image y runs downwards = -y (1 - v); LookAt mirrors x for a camera looking down -z with up = +y
+    assert np.abs(rgb[..., 2]).max() < 1e-6                  # exactly 0 before the RGB -> XYZ -> RGB round trip of the film
+    uu = rgb[16, :, 0]
+    assert np.allclose(np.sort(uu), u, atol=0.02) and np.allclose(np.sort(rgb[:, 16, 1]), u, atol=0.02)
+
+
+# ------------------------------------------------------------------ GPU parity
+def textured_scene(be, img):
+    """checkerboard floor (mesh with uvs), image-mapped sphere, uv-mapped mesh without uvs (default uvs), nested texture on a
+    rough glass sphere with textured roughness, a mirror that shows textured surfaces (differentials through mod.rs:58-84),
+    thin-lens camera (differentials of the lens branch, camera/mod.rs:158-179)"""
+    b = SceneBuilder(be)
+    b.texture("chk", "spectrum", "checkerboard", uscale=6.0, vscale=6.0, tex1=(0.15, 0.15, 0.2), tex2=(0.8, 0.75, 0.7))
+    b.texture("img", "spectrum", "imagemap", texels=img, wrap="repeat", uscale=2.0, vscale=2.0)
+    b.texture("imgc", "spectrum", "imagemap", texels=img, wrap="clamp", scale=0.8)
+    b.texture("grid", "spectrum", "uv", uscale=4.0, vscale=4.0)
+    b.texture("rough", "float", "checkerboard", uscale=5.0, vscale=3.0, tex1=0.05, tex2=0.4)
+    b.texture("nest", "spectrum", "checkerboard", uscale=2.0, vscale=2.0, tex1="grid", tex2="imgc")
+    b.light_source("point", I=(60, 60, 60), from_=(1, -2, 4))
+    b.light_source("distant", L=(1.0, 0.9, 0.8), from_=(-1, -1, 2), to=(0, 0, 0))
+    b.material("matte", Kd="chk", sigma="rough")
+    b.shape("trianglemesh", P=[(-6, -6, -1), (6, -6, -1), (6, 6, -1), (-6, 6, -1)], uv=[0, 0, 1, 0, 1, 1, 0, 1], indices=[0, 1, 2, 0, 2, 3])
+    b.attribute_begin(); b.material("matte", Kd="nest"); b.translate((0, 3, 0.5)); b.rotate(90, (1, 0, 0))
+    b.shape("trianglemesh", P=[(-3, -1.5, 0), (3, -1.5, 0), (3, 1.5, 0), (-3, 1.5, 0)], indices=[0, 1, 2, 0, 2, 3]); b.attribute_end()       # no uvs: defaults
+    b.attribute_begin(); b.material("plastic", Kd="img", Ks=(0.2, 0.2, 0.2), roughness="rough"); b.translate((-1.6, 0, -0.3)); b.rotate(25, (0, 0, 1)); b.shape("sphere", radius=0.7); b.attribute_end()
+    b.attribute_begin(); b.material("mirror", Kr=(0.9, 0.9, 0.9)); b.translate((0.2, 0.8, -0.2)); b.shape("sphere", radius=0.8); b.attribute_end()
+    b.attribute_begin(); b.material("glass", Kr="grid", Kt="chk", uroughness="rough", vroughness=0.3, eta=1.4); b.translate((1.7, -0.4, -0.4)); b.shape("sphere", radius=0.6); b.attribute_end()
+    b.attribute_begin(); b.material("metal", eta="img", k=(3.5, 2.5, 2.0), roughness="rough"); b.translate((-0.2, -1.3, -0.6)); b.shape("sphere", radius=0.4); b.attribute_end()
+    b.attribute_begin(); b.material("matte", Kd=(0, 0, 0)); b.area_light_source("diffuse", L=(6, 6, 6)); b.translate((-2, -1, 3)); b.reverse_orientation(); b.shape("sphere", radius=0.4); b.attribute_end()
+    cam = PerspectiveCamera.look_at(be, (0, -6, 2.2), (0, 0, -0.2), (0, 0, 1), (80, 56), fov=40.0, lens_radius=0.05, focal_dist=6.3)
+    return b, cam, (80, 56)
+
+
+def _img():
+    rng = np.random.default_rng(21)
+    y, x = np.mgrid[0:12, 0:20]
+    base = np.stack([np.sin(x * 0.9) * 0.5 + 0.5, np.cos(y * 0.7) * 0.5 + 0.5, ((x + y) % 3) / 2.0], axis=-1)
+    return (base * 0.8 + rng.random((12, 20, 3)) * 0.2).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_texture_evaluate_on_device(gpu, orc_det):
+    img = _img()
+    rng = np.random.default_rng(5)
+    rows = np.concatenate([(rng.random((20000, 2)) * 8 - 3), rng.standard_normal((20000, 4)) * np.exp(rng.uniform(-9, 1, (20000, 1)))], axis=1).astype(np.float32)
+    rows[:500, 2:] = 0.0
+    scs = []
+    for be in (gpu, orc_det):
+        b, ids = texture_zoo(be, img)
+        scs.append(b.create_scene())
+    for name, tid in ids.items():
+        a, o = tex_eval(scs[0], tid, rows), tex_eval(scs[1], tid, rows)
+        assert np.array_equal(a.view(np.uint32), o.view(np.uint32)), name
+
+
+MEGA, WAVE = A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,integ,sampler,pipeline", [
+    ("path mega", PathIntegrator.new(5, 1.0), RandomSampler(4, 0, indexed=True), MEGA),
+    ("path wavefront", PathIntegrator.new(5, 1.0), RandomSampler(4, 0, indexed=True), WAVE),
+    ("path tile-serial", PathIntegrator.new(3, 1.0), RandomSampler(1, 0), MEGA),
+    ("direct", DirectLightingIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA),
+    ("whitted", WhittedIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA),
+])
+def test_textured_render_matches_oracle(gpu, orc_det, name, integ, sampler, pipeline):
+    from test_gpu_parity import assert_film_equal, render_pair
+    img = _img()
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, lambda be: textured_scene(be, img), integ, sampler, pipeline)
+    assert_film_equal(px, pxo, st["spill_samples"], name)
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+    assert rgb.std() > 0.05                                  # not a blank frame
