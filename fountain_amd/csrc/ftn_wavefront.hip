@@ -791,7 +791,9 @@ __global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, cons
     const float fx = fminf(fmaxf((a.x - S.root_lo[0]) / ex, 0.0f), 0.999f) * sc, fy = fminf(fmaxf((a.y - S.root_lo[1]) / ey, 0.0f), 0.999f) * sc, fz = fminf(fmaxf((a.z - S.root_lo[2]) / ez, 0.0f), 0.999f) * sc;
     const uint32_t m = spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
     const uint32_t oct = (b.x < 0.0f ? 1u : 0u) | (b.y < 0.0f ? 2u : 0u) | (b.z < 0.0f ? 4u : 0u);
-    keys[i] = mode == 1 ? ((oct << (3 * bits)) | m) : ((m << 3) | oct);
+    const float ax = fabsf(b.x), ay = fabsf(b.y), az = fabsf(b.z);
+    const uint32_t dir6 = (oct << 3) | (ax > ay ? 1u : 0u) | (ay > az ? 2u : 0u) | (ax > az ? 4u : 0u);
+    keys[i] = mode == 1 ? ((oct << (3 * bits)) | m) : (mode == 3 ? ((m << 6) | dir6) : ((m << 3) | oct));
 }
 
 struct WavefrontState {
@@ -936,9 +938,9 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                     if (pass) hipLaunchKernelGGL(k_wf_ray_keys<true>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, q, cnt, k_in, sort_mode, bits);
                     else hipLaunchKernelGGL(k_wf_ray_keys<false>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, q, cnt, k_in, sort_mode, bits);
                     size_t need = 0;
-                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, q, out, (int)cnt, 0, (int)(3 * bits + 3), stream));
+                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, q, out, (int)cnt, 0, (int)(3 * bits + (sort_mode == 3 ? 6 : 3)), stream));
                     if (need > st->sort_tmp_bytes) { if (st->sort_tmp) (void)hipFree(st->sort_tmp); WF_TRY(hipMalloc(&st->sort_tmp, need)); st->sort_tmp_bytes = need; }
-                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, k_in, k_out, q, out, (int)cnt, 0, (int)(3 * bits + 3), stream));
+                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, k_in, k_out, q, out, (int)cnt, 0, (int)(3 * bits + (sort_mode == 3 ? 6 : 3)), stream));
                     WF_TRY(hipMemcpyAsync(q, out, (size_t)cnt * 4, hipMemcpyDeviceToDevice, stream));
                 }
             }

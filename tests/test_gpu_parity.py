@@ -264,6 +264,33 @@ def test_config4_like_full_resolution_tile_subset(gpu, orc_det):
     assert 0 < st["camera_samples"] < 20 * 256 * 4                                           # some tiles are 16x8
 
 
+def test_config5_full_size(gpu, orc_det):
+    """BASELINE config 5 at its full size (2309 baked copies = 10,002,588 triangles, 4096x4096 film, the bench.py workload):
+    (a) 12 tiles spread over the film against the oracle, bit for bit, with equal ray counts;
+    (b) size-independent properties over the WHOLE film: two interleaved tile shards (what two GPUs would render) merged by
+        addition equal the unsharded film, and a second render of the same samples is bit-identical (no race in the film sums)."""
+    make = lambda be: scenes.instanced_cubes(be, n_copies=2309, res=(4096, 4096))
+    n_tiles = Film(gpu, (4096, 4096)).tile_count()
+    assert n_tiles == 256 * 256
+    px, st = _tile_subset_parity(gpu, orc_det, make, 1, (256 * 100 + 31, 2731, 12))
+    assert st["camera_samples"] == 12 * 256
+    b, cam, res = make(gpu)
+    sc = b.create_scene()
+    assert sc.info()["n_prims"] == 10002588
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    smp = lambda: RandomSampler(4096, 0, indexed=True, first_sample=7, sample_count=1)
+    whole, again, merged = Film(gpu, res), Film(gpu, res), Film(gpu, res)
+    st_w = si.render_parallel(sc, whole, smp(), pipeline=WAVE)
+    si.render_parallel(sc, again, smp(), pipeline=WAVE)
+    st_a = si.render_parallel(sc, merged, smp(), tiles=(0, 2, 0), pipeline=WAVE)
+    st_b = si.render_parallel(sc, merged, smp(), tiles=(1, 2, 0), pipeline=WAVE)
+    assert np.array_equal(bits(whole.pixels), bits(again.pixels))
+    assert st_a["rays_closest"] + st_b["rays_closest"] == st_w["rays_closest"] and st_a["rays_any"] + st_b["rays_any"] == st_w["rays_any"]
+    assert st_w["camera_samples"] == 4096 * 4096
+    assert_film_equal(merged.pixels, whole.pixels, st_w["spill_samples"], "config 5 shards")
+    assert whole.pixels[..., 3].min() >= 1.0
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_specular_glass_reports_unsupported(gpu):
     b = SceneBuilder(gpu)
