@@ -3,12 +3,14 @@
  * write_exr / read_exr produce and consume (src/imageio/exr.rs:11-87).  The reference delegates the container to the `exr`
  * crate (RLE-compressed scanline blocks); this writer emits the same layer (name "image", channels B G R, FLOAT, increasing
  * line order) with NO_COMPRESSION, which every OpenEXR reader accepts and which keeps the sample bits exactly as rendered.
- * The reader handles NO_COMPRESSION and RLE scanline files with FLOAT or HALF channels (what the writer above and the
- * reference's writer produce).
+ * The reader handles NO_COMPRESSION, RLE, ZIPS and ZIP scanline files with FLOAT or HALF channels (what the writer above and the
+ * reference's writer produce, plus the usual encoding of environment maps and textures found in PBRT scenes; zlib inflates).
  */
 #include "../../include/fountain_hip.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <zlib.h>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,6 +38,14 @@ float half_to_float(uint16_t h) {
     float f; memcpy(&f, &u, 4); return f;
 }
 
+/* the byte predictor and the two-halves interleave shared by OpenEXR's RLE and ZIP blocks */
+void unpredict(std::vector<unsigned char>& tmp, std::vector<unsigned char>& out) {
+    const size_t n = tmp.size();
+    for (size_t i = 1; i < n; i++) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);
+    out.resize(n);
+    const size_t half = (n + 1) / 2;
+    for (size_t i = 0, a = 0, b = half; i < n;) { out[i++] = tmp[a++]; if (i < n) out[i++] = tmp[b++]; }
+}
 /* OpenEXR RLE block: run-length bytes, then predictor + interleave undone */
 bool rle_decode(const unsigned char* in, size_t n_in, std::vector<unsigned char>& out, size_t n_out) {
     std::vector<unsigned char> tmp; tmp.reserve(n_out);
@@ -46,10 +56,14 @@ bool rle_decode(const unsigned char* in, size_t n_in, std::vector<unsigned char>
         else { if (p >= n_in) return false; tmp.insert(tmp.end(), (size_t)c + 1, in[p]); p++; }
     }
     if (tmp.size() != n_out) return false;
-    for (size_t i = 1; i < n_out; i++) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);
-    out.resize(n_out);
-    const size_t half = (n_out + 1) / 2;
-    for (size_t i = 0, a = 0, b = half; i < n_out;) { out[i++] = tmp[a++]; if (i < n_out) out[i++] = tmp[b++]; }
+    unpredict(tmp, out);
+    return true;
+}
+bool zip_decode(const unsigned char* in, size_t n_in, std::vector<unsigned char>& out, size_t n_out) {
+    std::vector<unsigned char> tmp(n_out);
+    uLongf got = (uLongf)n_out;
+    if (uncompress(tmp.data(), &got, in, (uLong)n_in) != Z_OK || got != n_out) return false;
+    unpredict(tmp, out);
     return true;
 }
 
@@ -128,7 +142,8 @@ int ftn_exr_read(const char* path, uint32_t* w_out, uint32_t* h_out, float* rgb_
     }
     const int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
     if (w <= 0 || h <= 0) return io_fail(FTN_ERR_INVALID_ARGUMENT, "OpenEXR file has no dataWindow");
-    if (compression != 0 && compression != 1) return io_fail(FTN_ERR_UNSUPPORTED, "only NO_COMPRESSION and RLE OpenEXR scanline files are supported");
+    if (compression < 0 || compression > 3) return io_fail(FTN_ERR_UNSUPPORTED, "only NO_COMPRESSION, RLE, ZIPS and ZIP OpenEXR scanline files are supported (not PIZ / PXR24 / B44 / DWA)");
+    const int64_t lines_per_block = compression == 3 ? 16 : 1;
     if (w_out) *w_out = (uint32_t)w;
     if (h_out) *h_out = (uint32_t)h;
     if (!rgb_out) return FTN_OK;
@@ -141,21 +156,29 @@ int ftn_exr_read(const char* path, uint32_t* w_out, uint32_t* h_out, float* rgb_
     }
     if (ci[0] < 0 || ci[1] < 0 || ci[2] < 0) return io_fail(FTN_ERR_INVALID_ARGUMENT, "OpenEXR file lacks R, G or B");
     (void)line_order;                                       /* every block carries its own y */
-    if (p + (size_t)h * 8 > buf.size()) return io_fail(FTN_ERR_INVALID_ARGUMENT, "truncated OpenEXR offset table");
     std::vector<unsigned char> raw;
-    for (int64_t b = 0; b < h; b++) {
+    const int64_t n_blocks = (h + lines_per_block - 1) / lines_per_block;
+    if (p + (size_t)n_blocks * 8 > buf.size()) return io_fail(FTN_ERR_INVALID_ARGUMENT, "truncated OpenEXR offset table");
+    for (int64_t b = 0; b < n_blocks; b++) {
         uint64_t off; memcpy(&off, &buf[p + (size_t)b * 8], 8);
         if (off + 8 > buf.size()) return io_fail(FTN_ERR_INVALID_ARGUMENT, "truncated OpenEXR scanline");
         int32_t y, n; memcpy(&y, &buf[off], 4); memcpy(&n, &buf[off + 4], 4);
         if (n < 0 || off + 8 + (size_t)n > buf.size() || y < dw[1] || y > dw[3]) return io_fail(FTN_ERR_INVALID_ARGUMENT, "corrupt OpenEXR scanline");
+        const int64_t lines = std::min<int64_t>(lines_per_block, (int64_t)dw[3] - y + 1);
+        const size_t raw_bytes = row_bytes * (size_t)lines;
         const unsigned char* data = &buf[off + 8];
-        if (compression == 1 && (size_t)n < row_bytes) { if (!rle_decode(data, (size_t)n, raw, row_bytes)) return io_fail(FTN_ERR_INVALID_ARGUMENT, "corrupt RLE block"); data = raw.data(); }
-        else if ((size_t)n != row_bytes) return io_fail(FTN_ERR_INVALID_ARGUMENT, "unexpected OpenEXR scanline size");
-        float* dst = rgb_out + (size_t)(y - dw[1]) * (size_t)w * 3;
-        for (int k = 0; k < 3; k++) {
-            const unsigned char* src = data + ch_off[ci[k]];
-            if (chans[ci[k]].type == 2) for (int64_t x = 0; x < w; x++) memcpy(&dst[3 * x + k], src + 4 * x, 4);
-            else for (int64_t x = 0; x < w; x++) { uint16_t hv; memcpy(&hv, src + 2 * x, 2); dst[3 * x + k] = half_to_float(hv); }
+        if (compression != 0 && (size_t)n < raw_bytes) {          /* a block that does not shrink is stored raw */
+            const bool ok = compression == 1 ? rle_decode(data, (size_t)n, raw, raw_bytes) : zip_decode(data, (size_t)n, raw, raw_bytes);
+            if (!ok) return io_fail(FTN_ERR_INVALID_ARGUMENT, "corrupt compressed OpenEXR block");
+            data = raw.data();
+        } else if ((size_t)n != raw_bytes) return io_fail(FTN_ERR_INVALID_ARGUMENT, "unexpected OpenEXR block size");
+        for (int64_t ly = 0; ly < lines; ly++) {
+            float* dst = rgb_out + (size_t)(y + ly - dw[1]) * (size_t)w * 3;
+            for (int k = 0; k < 3; k++) {
+                const unsigned char* src = data + (size_t)ly * row_bytes + ch_off[ci[k]];
+                if (chans[ci[k]].type == 2) for (int64_t x = 0; x < w; x++) memcpy(&dst[3 * x + k], src + 4 * x, 4);
+                else for (int64_t x = 0; x < w; x++) { uint16_t hv; memcpy(&hv, src + 2 * x, 2); dst[3 * x + k] = half_to_float(hv); }
+            }
         }
     }
     return FTN_OK;

@@ -399,7 +399,7 @@ int ftn_ply_load(const char* path, uint32_t* n_vertices, uint32_t* n_triangles, 
 int ftn_film_resolve_device(const void* device_pixels, size_t n_pixels, void* device_rgb_out, void* stream);
 /* write_exr / read_exr (src/imageio/exr.rs:11-87): scanline OpenEXR, FLOAT channels R G B, layer "image"; rgb is row-major,
  * 3 floats per pixel.  The writer emits NO_COMPRESSION blocks (the reference's `exr` crate writes RLE: same samples, same layer);
- * the reader accepts NO_COMPRESSION and RLE scanline files with FLOAT or HALF channels.  ftn_exr_read with rgb_out == NULL only
+ * the reader accepts NO_COMPRESSION, RLE, ZIPS and ZIP scanline files with FLOAT or HALF channels.  ftn_exr_read with rgb_out == NULL only
  * reports the size.                                                                                                        */
 int ftn_exr_write(const char* path, const float* rgb, uint32_t width, uint32_t height);
 int ftn_exr_read(const char* path, uint32_t* width, uint32_t* height, float* rgb_out);

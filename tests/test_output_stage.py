@@ -109,6 +109,40 @@ def test_exr_reader_rle_and_half(ftn, tmp_path, half):
     assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
 
 
+@pytest.mark.parametrize("comp,lines", [(2, 1), (3, 16)])
+def test_exr_reader_zip(ftn, tmp_path, comp, lines):
+    """ZIPS (one scanline per block) and ZIP (16 per block, the last one short): the usual encodings of PBRT scenes' EXR textures"""
+    import zlib
+    w, h = 21, 37
+    rng = np.random.default_rng(comp)
+    img = (rng.random((h, w, 3)) * np.linspace(0.1, 4, w)[None, :, None]).astype(np.float32)
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chl = b"".join(c.encode() + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for c in "BGR") + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    hdr = bytes([0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0]) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp])) + \
+        attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+        attr("pixelAspectRatio", "float", struct.pack("<f", 1)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1)) + b"\0"
+    blocks = []
+    for y0 in range(0, h, lines):
+        raw = b"".join(img[y, :, "RGB".index(c)].astype("<f4").tobytes() for y in range(y0, min(y0 + lines, h)) for c in "BGR")
+        t = bytes(raw[0::2]) + bytes(raw[1::2])                                      # two halves
+        d = bytearray(len(t)); d[0] = t[0]
+        for i in range(1, len(t)):
+            d[i] = (t[i] - t[i - 1] + 128) & 255                                     # byte predictor
+        z = zlib.compress(bytes(d))
+        data = z if len(z) < len(raw) else raw
+        blocks.append(struct.pack("<ii", y0, len(data)) + data)
+    off, offs = len(hdr) + 8 * len(blocks), []
+    for blk in blocks:
+        offs.append(off); off += len(blk)
+    path = tmp_path / "z.exr"
+    path.write_bytes(hdr + struct.pack("<%dQ" % len(blocks), *offs) + b"".join(blocks))
+    got = read_exr(str(path), ftn)
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
+
+
 def test_exr_errors(ftn, tmp_path):
     with pytest.raises(FountainError):
         read_exr(str(tmp_path / "missing.exr"), ftn)
