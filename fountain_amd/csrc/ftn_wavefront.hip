@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     const uint32_t lane = lane_id();
     const uint32_t np = W.n_paths;
     TravCount tc{0, 0};
+    uint32_t w_node_steps = 0, w_leaf_steps = 0;   /* COUNT only: wave-level step counts -> SIMD lane utilisation (FTN_WF_DEBUG) */
     uint32_t mode = TM_IDLE;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
     /* per-wave chunk: few queue-head atomics, but small enough that the tail spreads over all waves */
@@ -249,6 +250,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
             /* ---- node steps: `node_burst` of them per control round (lanes that reach a leaf or finish sit out the rest) */
             for (uint32_t burst = 0; burst < node_burst; burst++) {
+                if (COUNT && __ballot(mode == TM_NODE && !finish) != 0) w_node_steps++;
                 if (mode == TM_NODE && !finish) {
                     float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
                     pin4(nlo); pin4(nhi);
@@ -269,6 +271,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             }
         } else {
             /* ---- leaf step: one primitive per lane */
+            if (COUNT) w_leaf_steps++;
             if (mode == TM_LEAF) {
                 const uint32_t prim = lp;
                 float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
@@ -297,6 +300,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         if (lane == 0) {
             if (n) atomicAdd(&stats->nodes_visited, n); if (p) atomicAdd(&stats->prims_tested, p);
             if (ANY) { if (n) atomicAdd(&stats->nodes_any, n); if (p) atomicAdd(&stats->prims_any, p); }
+            atomicAdd(&W.counters[CTR(6)], w_node_steps); atomicAdd(&W.counters[CTR(7)], w_leaf_steps);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
@@ -947,6 +951,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             if (it >= P.max_depth) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
                 WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 WF_TRY(hipStreamSynchronize(stream));
+                if (count && knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] wave steps so far: node %u leaf %u\n", st->host_counters[CTR(6)], st->host_counters[CTR(7)]);
                 if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
             }
         }
