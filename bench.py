@@ -187,7 +187,7 @@ def cpu_baseline(desc, cam, film, n_cpu_tiles, n_tiles):
     rays = st["rays_closest"] + st["rays_any"]
     secs = st["kernel_ms"] * 1e-3
     return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d of %d tiles (every %dth), 1 spp, same scene/integrator; %.1f s of wall time on %d threads; C++ restatement of fountain's CPU path "
+            "sample": "%d of the %d film tiles (tile stride %d), 1 spp, same scene/integrator; %.1f s of wall time on %d threads; C++ restatement of fountain's CPU path "
                       "(oracle/), transcendentals from libm; oracle BVH build %.0f s not counted" % (n_cpu_tiles, n_tiles, stride, secs, cores, build_s)}
 
 
