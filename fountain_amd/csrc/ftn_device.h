@@ -3,7 +3,9 @@
  * per-lane routines (traversal, intersection, shading geometry, BSDFs, lights, sampler, camera, film).
  *
  * Layout in HBM (all built by ftn_scene_create, BVH primitive order):
- *   nodes      2 x float4 per LinearBVHNode: {bmin.xyz, bits(idx)} {bmax.xyz, bits(n_prims | axis<<16 | leaf<<24)}
+ *   nodes      2 x float4 per LinearBVHNode: {min.x, max.x, min.y, max.y} {min.z, max.z, bits(idx), bits(n_prims | axis<<16 | leaf<<24)}
+ *              (each axis' (min, max) pair sits in an even/odd register pair after the two dwordx4 loads, which is what the
+ *               packed-f32 subtract / multiply of the slab test consume: no register shuffling per node visit)
  *   geom       3 x float4 per primitive    : triangle {p0, bits(flags)} {p1, bits(shape idx)} {p2, 0}
  *                                            sphere   {0,0,0, bits(flags)} {0,0,0, bits(sphere idx)} {..}
  *              (vertices pre-gathered, so a leaf test is one 48-byte read: the reference chases
@@ -97,10 +99,17 @@ __device__ inline DRay spawn_ray_to_hit(const DSurfHit& a, const DSurfHit& to) {
 
 /* ------------------------------------------------------------------ Bounds3f::intersect_test: bounds.rs:214-233
  * inv = 1/dir is the value the reference recomputes at every node. */
+/* the same test on a node record as stored in HBM: a = {min.x, max.x, min.y, max.y}, b = {min.z, max.z, idx, meta} */
+__device__ inline bool slab_test(float4 nlo, float4 nhi, V3 o, V3 inv, float t_max);
+__device__ inline bool slab_test_node(float4 a, float4 b, V3 o, V3 inv, float t_max) {
+    return slab_test(make_float4(a.x, a.z, b.x, 0.0f), make_float4(a.y, a.w, b.y, 0.0f), o, inv, t_max);
+}
 __device__ inline bool slab_test(float4 nlo, float4 nhi, V3 o, V3 inv, float t_max) {
-    /* Branch-free form of the reference's loop with its three early `return None`s: the running t0/t1 of axis i only depend on
-     * axes <= i, so OR-ing the three `t0 > t1` tests gives the same boolean.  (With the early exits the compiler sinks the loads
-     * of the y/z bounds behind the x test: three dependent memory round trips per node instead of one.) */
+    /* Branch-free form of the reference's loop with its three early `return None`s.  The running t0 only grows and t1 only
+     * shrinks (an update happens only when the comparison is true, which also keeps NaNs from 0 * inf out of t0 / t1 -- exactly
+     * what fmaxf / fminf do), so `t0 > t1` after any axis implies `t0 > t1` after the last one: testing once at the end returns
+     * the same boolean as the three early exits.  (With the early exits the compiler sinks the loads of the y/z bounds behind the
+     * x test: three dependent memory round trips per node instead of one.) */
     const float k = 1.0f + 2.0f * gamma_n(3);
     float tnx = (nlo.x - o.x) * inv.x, tfx = (nhi.x - o.x) * inv.x;
     float tny = (nlo.y - o.y) * inv.y, tfy = (nhi.y - o.y) * inv.y;
@@ -109,10 +118,9 @@ __device__ inline bool slab_test(float4 nlo, float4 nhi, V3 o, V3 inv, float t_m
     if (tny > tfy) { float s = tny; tny = tfy; tfy = s; }
     if (tnz > tfz) { float s = tnz; tnz = tfz; tfz = s; }
     tfx *= k; tfy *= k; tfz *= k;
-    const float t0x = fmax_(0.0f, tnx), t1x = fmin_(t_max, tfx);
-    const float t0y = fmax_(t0x, tny), t1y = fmin_(t1x, tfy);
-    const float t0z = fmax_(t0y, tnz), t1z = fmin_(t1y, tfz);
-    return !((t0x > t1x) | (t0y > t1y) | (t0z > t1z));
+    const float t0 = fmax_(fmax_(fmax_(0.0f, tnx), tny), tnz);
+    const float t1 = fmin_(fmin_(fmin_(t_max, tfx), tfy), tfz);
+    return !(t0 > t1);
 }
 /* keeps a loaded float4 whole: stops the compiler from splitting / sinking its dword loads behind later branches */
 __device__ inline void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
@@ -262,12 +270,12 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
     const uint32_t neg = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
     int sp = 0; uint32_t cur = 0; bool found = false;
     for (;;) {
-        float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
-        pin4(nlo); pin4(nhi);
+        float4 na = S.nodes[2 * cur], nb = S.nodes[2 * cur + 1];
+        pin4(na); pin4(nb);
         if (COUNT) tc->nodes++;
         bool descend = false;
-        if (slab_test(nlo, nhi, ray.o, inv, ray.t_max)) {
-            const uint32_t idx = __float_as_uint(nlo.w), meta = __float_as_uint(nhi.w);
+        if (slab_test_node(na, nb, ray.o, inv, ray.t_max)) {
+            const uint32_t idx = __float_as_uint(nb.z), meta = __float_as_uint(nb.w);
             if (meta >> 24) {   /* leaf */
                 const uint32_t n = meta & 0xffffu;
                 for (uint32_t i = 0; i < n; i++) {

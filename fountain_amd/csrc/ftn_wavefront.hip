@@ -252,12 +252,12 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             for (uint32_t burst = 0; burst < node_burst; burst++) {
                 if (COUNT && __ballot(mode == TM_NODE && !finish) != 0) w_node_steps++;
                 if (mode == TM_NODE && !finish) {
-                    float4 nlo = S.nodes[2 * cur], nhi = S.nodes[2 * cur + 1];
-                    pin4(nlo); pin4(nhi);
+                    float4 na = S.nodes[2 * cur], nb = S.nodes[2 * cur + 1];
+                    pin4(na); pin4(nb);
                     if (COUNT) tc.nodes++;
                     bool pop = true;
-                    if (slab_test(nlo, nhi, o, inv, t_max)) {
-                        const uint32_t idx = __float_as_uint(nlo.w), meta = __float_as_uint(nhi.w);
+                    if (slab_test_node(na, nb, o, inv, t_max)) {
+                        const uint32_t idx = __float_as_uint(nb.z), meta = __float_as_uint(nb.w);
                         if (meta >> 24) { lp = idx; lp_end = idx + (meta & 0xffffu); mode = TM_LEAF; pop = false; }
                         else {
                             const uint32_t axis = (meta >> 16) & 3u;
@@ -337,7 +337,7 @@ __device__ inline SlabOut slab_test2(float4 lo, float4 hi, V3 o, V3 inv, float t
     const float t0x = fmax_(0.0f, tnx), t1x = fmin_(t_max, tfx);
     const float t0y = fmax_(t0x, tny), t1y = fmin_(t1x, tfy);
     const float t0z = fmax_(t0y, tnz), t1z = fmin_(t1y, tfz);
-    SlabOut r; r.hit = !((t0x > t1x) | (t0y > t1y) | (t0z > t1z)); r.t0 = t0z;
+    SlabOut r; r.hit = !(t0z > t1z); r.t0 = t0z;      /* see slab_test: the last comparison subsumes the earlier ones */
     return r;
 }
 
