@@ -3,7 +3,9 @@
  * per-lane routines (traversal, intersection, shading geometry, BSDFs, lights, sampler, camera, film).
  *
  * Layout in HBM (all built by ftn_scene_create, BVH primitive order):
- *   nodes      2 x float4 per LinearBVHNode: {min.x, max.x, min.y, max.y} {min.z, max.z, bits(idx), bits(n_prims | axis<<16 | leaf<<24)}
+ *   nodes      2 x float4 per LinearBVHNode: {min.x, max.x, min.y, max.y} {min.z, max.z, bits(link), bits(n_prims | onehot(axis)<<16 | leaf<<24)}
+ *              link = BYTE offset of the second child's record (interior; the first child is the next record) or first primitive (leaf):
+ *              traversal keeps byte offsets, so a node address is base + offset with no index arithmetic;
  *              (each axis' (min, max) pair sits in an even/odd register pair after the two dwordx4 loads, which is what the
  *               packed-f32 subtract / multiply of the slab test consume: no register shuffling per node visit)
  *   geom       3 x float4 per primitive    : triangle {p0, bits(flags)} {p1, bits(shape idx)} {p2, 0}
@@ -268,9 +270,11 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
     if (S.n_nodes == 0) return false;
     const V3 inv(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     const uint32_t neg = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
-    int sp = 0; uint32_t cur = 0; bool found = false;
+    int sp = 0; uint32_t cur = 0; bool found = false;                    /* cur: byte offset of the node record */
+    const uint32_t neg16 = neg << 16;
     for (;;) {
-        float4 na = S.nodes[2 * cur], nb = S.nodes[2 * cur + 1];
+        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur);
+        float4 na = rec[0], nb = rec[1];
         pin4(na); pin4(nb);
         if (COUNT) tc->nodes++;
         bool descend = false;
@@ -298,9 +302,8 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
                     }
                 }
             } else {
-                const uint32_t axis = (meta >> 16) & 3u;
-                if ((neg >> axis) & 1u) { st.push(sp++, cur + 1); cur = idx; }
-                else { st.push(sp++, idx); cur = cur + 1; }
+                if (meta & neg16) { st.push(sp++, cur + 32u); cur = idx; }       /* dir_is_neg[axis]: second child first */
+                else { st.push(sp++, idx); cur = cur + 32u; }
                 descend = true;
             }
         }

@@ -533,7 +533,10 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         const ftn_bvh_node& n = hs.nodes[i];
         /* slab pairs first: the x and y (min, max) pairs, then the z pair with the two index words (see ftn_device.h) */
         nodes[2 * i] = make_float4(n.bmin[0], n.bmax[0], n.bmin[1], n.bmax[1]);
-        nodes[2 * i + 1] = make_float4(n.bmin[2], n.bmax[2], ftn_det::u2f(n.idx), ftn_det::u2f((uint32_t)n.n_prims | ((uint32_t)n.axis << 16) | ((uint32_t)n.is_leaf << 24)));
+        /* interior: byte offset of the second child (the first child is the next record: +32); leaf: first primitive.
+         * meta: n_prims | one-hot split axis << 16 (matches the ray's dir_is_neg bits) | leaf << 24 */
+        const uint32_t link = n.is_leaf ? n.idx : n.idx * 32u;
+        nodes[2 * i + 1] = make_float4(n.bmin[2], n.bmax[2], ftn_det::u2f(link), ftn_det::u2f((uint32_t)n.n_prims | ((1u << n.axis) << 16) | ((uint32_t)n.is_leaf << 24)));
     }
     /* fat records (see DScene::fat): one per interior node, numbered in DFS order */
     std::vector<uint32_t> fat_id(hs.nodes.size(), 0xffffffffu);

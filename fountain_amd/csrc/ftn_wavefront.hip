@@ -194,7 +194,8 @@ template <bool ANY, bool COUNT, bool SPHERES>
 __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
                                                   DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t node_burst) {
     extern __shared__ uint32_t lds_stack[];
-    const LdsStack st{lds_stack + threadIdx.x, 256u};
+    uint32_t* const st_base = lds_stack + threadIdx.x;      /* [level][lane]; the stack pointer is kept as an LDS address */
+    uint32_t* sptr = st_base;
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
     const uint32_t np = W.n_paths;
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
     /* per-wave chunk: few queue-head atomics, but small enough that the tail spreads over all waves */
     { uint32_t c = count / (gridDim.x * 4u * 16u); c &= ~63u; chunk = c < 64u ? 64u : (c > chunk ? chunk : c); }
-    uint32_t rid = 0, cur = 0, neg = 0, lp = 0, lp_end = 0; int sp = 0;
+    uint32_t rid = 0, cur = 0 /* byte offset of the node record */, neg16 = 0, lp = 0, lp_end = 0;
     V3 o, inv, dperm; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kz = 0;
     int hprim = -1; float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f; bool found = false;
     V3 dorig;   /* only the sphere path needs the unpermuted direction */
@@ -230,12 +231,12 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
                 if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+                neg16 = (d.x < 0.0f ? 0x10000u : 0u) | (d.y < 0.0f ? 0x20000u : 0u) | (d.z < 0.0f ? 0x40000u : 0u);   /* dir_is_neg, aligned with the node's one-hot axis */
                 /* Triangle::intersect's per-ray constants (triangle.rs:189-205): permutation and shear depend on the ray only */
                 kz = max_dimension(vabs(d));
                 { const int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1; dperm = V3(d.get(kx), d.get(ky), d.get(kz)); }
                 sx = -dperm.x / dperm.z; sy = -dperm.y / dperm.z; sz = 1.0f / dperm.z;
-                sp = 0; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
+                sptr = st_base; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
                 mode = TM_NODE;
                 if (S.n_nodes == 0) {   /* empty scene: immediate miss */
                     if (ANY) W.occluded[rid] = 0; else { W.hit[r] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[r] = -1; }
@@ -252,7 +253,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             for (uint32_t burst = 0; burst < node_burst; burst++) {
                 if (COUNT && __ballot(mode == TM_NODE && !finish) != 0) w_node_steps++;
                 if (mode == TM_NODE && !finish) {
-                    float4 na = S.nodes[2 * cur], nb = S.nodes[2 * cur + 1];
+                    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur);
+                    float4 na = rec[0], nb = rec[1];
                     pin4(na); pin4(nb);
                     if (COUNT) tc.nodes++;
                     bool pop = true;
@@ -260,13 +262,13 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                         const uint32_t idx = __float_as_uint(nb.z), meta = __float_as_uint(nb.w);
                         if (meta >> 24) { lp = idx; lp_end = idx + (meta & 0xffffu); mode = TM_LEAF; pop = false; }
                         else {
-                            const uint32_t axis = (meta >> 16) & 3u;
-                            if ((neg >> axis) & 1u) { st.push(sp++, cur + 1); cur = idx; }
-                            else { st.push(sp++, idx); cur = cur + 1; }
+                            if (meta & neg16) { *sptr = cur + 32u; cur = idx; }      /* dir_is_neg[axis]: second child first */
+                            else { *sptr = idx; cur = cur + 32u; }
+                            sptr += 256;
                             pop = false;
                         }
                     }
-                    if (pop) { if (sp == 0) finish = true; else cur = st.pop(--sp); }
+                    if (pop) { if (sptr == st_base) finish = true; else { sptr -= 256; cur = *sptr; } }
                 }
             }
         } else {
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 if (hh) { found = true; t_max = t; hprim = (int)prim; hb0 = b0; hb1 = b1; hb2 = b2; }
                 lp++;
                 if (ANY && hh) finish = true;
-                else if (lp == lp_end) { if (sp == 0) finish = true; else { cur = st.pop(--sp); mode = TM_NODE; } }
+                else if (lp == lp_end) { if (sptr == st_base) finish = true; else { sptr -= 256; cur = *sptr; mode = TM_NODE; } }
             }
         }
         if (finish) {
