@@ -190,7 +190,7 @@ __device__ inline bool prim_hit(const DScene& S, uint32_t prim, float4 g0, float
  * with __ballot / __popcll prefix ranks as soon as `refill` of them are idle. */
 enum : uint32_t { TM_IDLE = 0, TM_NODE = 1, TM_LEAF = 2 };
 
-template <bool ANY, bool COUNT, bool SPHERES>
+template <bool ANY, bool COUNT, bool SPHERES, int BURST /* 0: node_burst is a runtime value */>
 __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
                                                   DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t node_burst) {
     extern __shared__ uint32_t lds_stack[];
@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         bool finish = false;
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
             /* ---- node steps: `node_burst` of them per control round (lanes that reach a leaf or finish sit out the rest) */
-            for (uint32_t burst = 0; burst < node_burst; burst++) {
+#pragma unroll
+            for (uint32_t burst = 0; burst < (BURST ? (uint32_t)BURST : node_burst); burst++) {
                 if (COUNT && __ballot(mode == TM_NODE && !finish) != 0) w_node_steps++;
                 if (mode == TM_NODE && !finish) {
                     const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur);
@@ -861,9 +862,11 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
         return;
     }
     lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
-#define FTN_TR(A, C, Sp) hipLaunchKernelGGL((k_wf_trace<A, C, Sp>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst)
-    if (any) { if (count) { if (spheres) FTN_TR(true, true, true); else FTN_TR(true, true, false); } else { if (spheres) FTN_TR(true, false, true); else FTN_TR(true, false, false); } }
-    else { if (count) { if (spheres) FTN_TR(false, true, true); else FTN_TR(false, true, false); } else { if (spheres) FTN_TR(false, false, true); else FTN_TR(false, false, false); } }
+#define FTN_TR(A, C, Sp, B) hipLaunchKernelGGL((k_wf_trace<A, C, Sp, B>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst)
+    const bool fixed = node_burst == 8 && !count && !knob("FTN_TRACE_NO_UNROLL", 0);      /* the default burst is compiled in (unrolled) */
+    if (fixed) { if (any) { if (spheres) FTN_TR(true, false, true, 8); else FTN_TR(true, false, false, 8); } else { if (spheres) FTN_TR(false, false, true, 8); else FTN_TR(false, false, false, 8); } }
+    else if (any) { if (count) { if (spheres) FTN_TR(true, true, true, 0); else FTN_TR(true, true, false, 0); } else { if (spheres) FTN_TR(true, false, true, 0); else FTN_TR(true, false, false, 0); } }
+    else { if (count) { if (spheres) FTN_TR(false, true, true, 0); else FTN_TR(false, true, false, 0); } else { if (spheres) FTN_TR(false, false, true, 0); else FTN_TR(false, false, false, 0); } }
 #undef FTN_TR
 }
 
