@@ -483,36 +483,50 @@ __device__ inline uint32_t wf_class_of(const RenderParams& P, const WfBuffers& W
     if (mat < 0) return 7u;
     return 2u + P.S.materials[mat].type;
 }
-/* ONE pass: each class owns a segment of `seg_cap` slots in q_sorted (worst case: every path in one class), filled with one
- * global atomic per workgroup and class.  The shade kernel derives the 256-aligned virtual layout from the 8 counts itself. */
+/* Each class owns a segment of `seg_cap` slots in q_sorted (worst case: every path in one class).  A workgroup classifies all of
+ * its rounds first (class codes and per-wave counts stay in LDS), reserves its slots with ONE global atomic per class -- with one
+ * atomic per class and round the kernel ran at the rate of same-address atomics (65 k of them on the busiest counter) -- and
+ * then writes its paths.  The shade kernel derives the 256-aligned virtual layout from the 8 counts itself. */
+#define WF_CLS_ROUNDS 32
 __global__ void __launch_bounds__(256) k_wf_classify(RenderParams P, WfBuffers W, int in_q) {
-    __shared__ uint32_t s_cnt[WF_NCLASS][4];
+    __shared__ unsigned char s_cls[WF_CLS_ROUNDS][256];
+    __shared__ uint32_t s_cnt[WF_CLS_ROUNDS][WF_NCLASS][4];        /* per round, class, wave */
+    __shared__ uint32_t s_pre[WF_CLS_ROUNDS][WF_NCLASS];           /* slots of the class used by earlier rounds of this workgroup */
     __shared__ uint32_t s_base[WF_NCLASS];
     const uint32_t count = W.counters[CTR(in_q == 0 ? 0 : 1)];
     const uint32_t stride = gridDim.x * 256u, rounds = (count + stride - 1) / stride;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    for (uint32_t round = 0; round < rounds; round++) {
-        const uint32_t qi = round * stride + blockIdx.x * 256u + threadIdx.x;
-        const bool have = qi < count;
-        uint32_t p = 0, c = WF_NCLASS;
-        if (have) { p = W.q_active[in_q][qi]; c = wf_class_of(P, W, p); }
-        unsigned long long mine = 0;
+    for (uint32_t r0 = 0; r0 < rounds; r0 += WF_CLS_ROUNDS) {
+        const uint32_t nr = rounds - r0 < WF_CLS_ROUNDS ? rounds - r0 : WF_CLS_ROUNDS;
+        for (uint32_t r = 0; r < nr; r++) {                        /* 1: classify */
+            const uint32_t qi = (r0 + r) * stride + blockIdx.x * 256u + threadIdx.x;
+            uint32_t c = WF_NCLASS;
+            if (qi < count) c = wf_class_of(P, W, W.q_active[in_q][qi]);
+            s_cls[r][threadIdx.x] = (unsigned char)c;
 #pragma unroll
-        for (int k = 0; k < WF_NCLASS; k++) {
-            const unsigned long long m = __ballot(c == (uint32_t)k);
-            if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(m);
-            if (c == (uint32_t)k) mine = m;
+            for (int k = 0; k < WF_NCLASS; k++) {
+                const unsigned long long m = __ballot(c == (uint32_t)k);
+                if (lane == 0) s_cnt[r][k][wave] = (uint32_t)__popcll(m);
+            }
         }
         __syncthreads();
-        if (threadIdx.x < WF_NCLASS) {
-            const uint32_t k = threadIdx.x, tot = s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+        if (threadIdx.x < WF_NCLASS) {                             /* 2: reserve */
+            const uint32_t k = threadIdx.x; uint32_t tot = 0;
+            for (uint32_t r = 0; r < nr; r++) { s_pre[r][k] = tot; tot += s_cnt[r][k][0] + s_cnt[r][k][1] + s_cnt[r][k][2] + s_cnt[r][k][3]; }
             s_base[k] = tot ? atomicAdd(&W.cls[CTR(k)], tot) : 0u;
         }
         __syncthreads();
-        if (have) {
-            uint32_t off = s_base[c];
-            for (uint32_t w2 = 0; w2 < wave; w2++) off += s_cnt[c][w2];
-            W.q_sorted[(size_t)c * W.seg_cap + off + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = p;
+        for (uint32_t r = 0; r < nr; r++) {                        /* 3: write */
+            const uint32_t qi = (r0 + r) * stride + blockIdx.x * 256u + threadIdx.x;
+            const uint32_t c = s_cls[r][threadIdx.x];
+            unsigned long long mine = 0;
+#pragma unroll
+            for (int k = 0; k < WF_NCLASS; k++) { const unsigned long long m = __ballot(c == (uint32_t)k); if (c == (uint32_t)k) mine = m; }
+            if (c < WF_NCLASS) {
+                uint32_t off = s_base[c] + s_pre[r][c];
+                for (uint32_t w2 = 0; w2 < wave; w2++) off += s_cnt[r][c][w2];
+                W.q_sorted[(size_t)c * W.seg_cap + off + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = W.q_active[in_q][qi];
+            }
         }
         __syncthreads();
     }
