@@ -37,10 +37,10 @@ struct WfBuffers {
     uint32_t samples;           /* S */
     uint32_t first_sample;      /* 0-based index of this pass's first sample */
     /* rays / hits: index r in [0, n_paths) = continuation ray of path r, [n_paths, 2 n_paths) = MIS ray of path r - n_paths */
-    float4 *ray_o, *ray_d;      /* xyz (+ unused, t_max) */
+    float4 *ray;                /* 2 float4 per ray, adjacent (one 32-byte record = one line fetch when rays are read in sorted order): {o.xyz, -} {d.xyz, t_max} */
     float4* hit;                /* t, b0, b1, b2 */
     int* hit_prim;
-    float4 *sh_o, *sh_d;        /* shadow rays, per path */
+    float4 *sh;                 /* shadow rays, per path, same 32-byte record */
     unsigned char* occluded;    /* per path */
     float4 *beta;               /* beta.xyz, bits(pstate) */
     float4 *rad;                /* L.xyz, bits(light index of the pending direct term) */
@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         V2 p_lens = rng.next2();
         float time_u = rng.next();
         DRay ray = camera_ray(P.C, p_film, p_lens, time_u);
-        W.ray_o[i] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-        W.ray_d[i] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.t_max);
+        W.ray[2 * (size_t)(i)] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+        W.ray[2 * (size_t)(i) + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.t_max);
         W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
         W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             if (mode == TM_IDLE && rank < avail) {
                 rid = queue[chunk_next + rank];
                 const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
-                const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
+                const float4 a = ANY ? W.sh[2 * (size_t)(r)] : W.ray[2 * (size_t)(r)], b = ANY ? W.sh[2 * (size_t)(r) + 1] : W.ray[2 * (size_t)(r) + 1];
                 o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
                 if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, con
             if (mode == TM_IDLE && rank < avail) {
                 rid = queue[chunk_next + rank];
                 const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
-                const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
+                const float4 a = ANY ? W.sh[2 * (size_t)(r)] : W.ray[2 * (size_t)(r)], b = ANY ? W.sh[2 * (size_t)(r) + 1] : W.ray[2 * (size_t)(r) + 1];
                 o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
                 if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                     const int light_index = (int)__float_as_uint(lq.w);
                     const DLight& Lt = S.lights[light_index];
                     const DHit mh = load_hit(W, p + W.n_paths);
-                    const float4 mo = W.ray_o[p + W.n_paths], md = W.ray_d[p + W.n_paths];
+                    const float4 mo = W.ray[2 * (size_t)(p + W.n_paths)], md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
                     Rgb inc(0.0f);
                     if (mh.prim >= 0) {
                         const uint4 pi = S.prim_info[2 * mh.prim];
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                 W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);     /* path finished: final radiance */
                 W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));
             } else {
-                const float4 ro = W.ray_o[p], rdv = W.ray_d[p];
+                const float4 ro = W.ray[2 * (size_t)(p)], rdv = W.ray[2 * (size_t)(p) + 1];
                 DRay ray0; ray0.o = V3(ro.x, ro.y, ro.z); ray0.d = V3(rdv.x, rdv.y, rdv.z); ray0.t_max = rdv.w; ray0.time = 0.0f;
                 const DHit h = load_hit(W, p);
                 const bool hit = h.prim >= 0;
@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                     const int mat = (int)S.prim_info[2 * si.prim].x;
                     if (mat < 0) {
                         DRay nr = spawn_ray(si.hit, ray0.d);                       /* null bsdf: path.rs:77-81 */
-                        W.ray_o[p] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray_d[p] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
+                        W.ray[2 * (size_t)(p)] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray[2 * (size_t)(p) + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
                         push_closest = true;
                     } else {
                         DBsdf B;
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                                     float sp = bsdf_pdf(B, si.wo, ls.wi, flags);
                                     if (!f.is_black()) {
                                         DRay sr = spawn_ray_to_hit(si.hit, ls.p1);
-                                        W.sh_o[p] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f); W.sh_d[p] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.t_max);
+                                        W.sh[2 * (size_t)(p)] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f); W.sh[2 * (size_t)(p) + 1] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.t_max);
                                         ld = delta ? (f * ls.radiance / ls.pdf) : (f * ls.radiance * power_heuristic(ls.pdf, sp) / ls.pdf);
                                         ps |= PS_SHADOW; push_shadow = true;
                                     }
@@ -676,8 +676,8 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                                             }
                                             if (go) {
                                                 DRay mr = spawn_ray(si.hit, sc.wi);
-                                                W.ray_o[p + W.n_paths] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
-                                                W.ray_d[p + W.n_paths] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
+                                                W.ray[2 * (size_t)(p + W.n_paths)] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
+                                                W.ray[2 * (size_t)(p + W.n_paths) + 1] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
                                                 mis_f = f; mis_pdf = sc.pdf; ps |= PS_MIS; push_mis = true;
                                             }
                                         }
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                                     if (rng.next() < q) alive = false; else beta = beta / (1.0f - q);
                                 }
                                 if (alive) {
-                                    W.ray_o[p] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray_d[p] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
+                                    W.ray[2 * (size_t)(p)] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray[2 * (size_t)(p) + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
                                     bounces += 1; push_closest = true;
                                 }
                             } else alive = false;
@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, cons
     if (i >= count) return;
     const uint32_t rid = queue[i];
     const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + W.n_paths : rid);
-    const float4 a = ANY ? W.sh_o[r] : W.ray_o[r], b = ANY ? W.sh_d[r] : W.ray_d[r];
+    const float4 a = ANY ? W.sh[2 * (size_t)(r)] : W.ray[2 * (size_t)(r)], b = ANY ? W.sh[2 * (size_t)(r) + 1] : W.ray[2 * (size_t)(r) + 1];
     const float ex = S.root_hi[0] - S.root_lo[0], ey = S.root_hi[1] - S.root_lo[1], ez = S.root_hi[2] - S.root_lo[2];
     const float sc = (float)(1u << bits);
     const float fx = fminf(fmaxf((a.x - S.root_lo[0]) / ex, 0.0f), 0.999f) * sc, fy = fminf(fmaxf((a.y - S.root_lo[1]) / ey, 0.0f), 0.999f) * sc, fz = fminf(fmaxf((a.z - S.root_lo[2]) / ez, 0.0f), 0.999f) * sc;
@@ -850,8 +850,8 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     if (n <= st->cap_paths) return FTN_OK;
     wf_free(st);
     WfBuffers& W = st->W; int rc;
-    if ((rc = wf_alloc(st, &W.ray_o, 2 * n)) || (rc = wf_alloc(st, &W.ray_d, 2 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
-        (rc = wf_alloc(st, &W.sh_o, n)) || (rc = wf_alloc(st, &W.sh_d, n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
+    if ((rc = wf_alloc(st, &W.ray, 4 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
+        (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
         (rc = wf_alloc(st, &W.counters, 8 * 32))) return rc;
