@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     const uint32_t lane = lane_id();
     const uint32_t np = W.n_paths;
     TravCount tc{0, 0};
+    uint32_t w_idle_lanes = 0, w_leafwait_lanes = 0;
     uint32_t w_node_steps = 0, w_leaf_steps = 0;   /* COUNT only: wave-level step counts -> SIMD lane utilisation (FTN_WF_DEBUG) */
     uint32_t mode = TM_IDLE;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             /* ---- node steps: `node_burst` of them per control round (lanes that reach a leaf or finish sit out the rest) */
 #pragma unroll
             for (uint32_t burst = 0; burst < (BURST ? (uint32_t)BURST : node_burst); burst++) {
-                if (COUNT && __ballot(mode == TM_NODE && !finish) != 0) w_node_steps++;
+                if (COUNT && __ballot(mode == TM_NODE && !finish) != 0) { w_node_steps++; w_idle_lanes += (uint32_t)__popcll(__ballot(mode == TM_IDLE || finish)); w_leafwait_lanes += (uint32_t)__popcll(__ballot(mode == TM_LEAF)); }
                 if (mode == TM_NODE && !finish) {
                     const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur);
                     float4 na = rec[0], nb = rec[1];
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             if (n) atomicAdd(&stats->nodes_visited, n); if (p) atomicAdd(&stats->prims_tested, p);
             if (ANY) { if (n) atomicAdd(&stats->nodes_any, n); if (p) atomicAdd(&stats->prims_any, p); }
             atomicAdd(&W.counters[CTR(6)], w_node_steps); atomicAdd(&W.counters[CTR(7)], w_leaf_steps);
+            atomicAdd(&W.counters[CTR(8)], w_idle_lanes >> 6); atomicAdd(&W.counters[CTR(9)], w_leafwait_lanes >> 6);     /* in units of 64 lanes */
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
@@ -730,7 +732,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
 __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {                                                                         /* new pass: generate fills both queues densely */
-        for (int i = 0; i < 8; i++) W.counters[CTR(i)] = 0;
+        for (int i = 0; i < 16; i++) W.counters[CTR(i)] = 0;
         W.counters[CTR(0)] = W.samples * W.valid_per_sample; W.counters[CTR(2)] = W.samples * W.valid_per_sample;
         stats->camera_samples += (unsigned long long)W.samples * W.valid_per_sample;
     } else if (mode == 1) {                                                                  /* before shade */
@@ -854,7 +856,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.counters, 8 * 32))) return rc;
+        (rc = wf_alloc(st, &W.counters, 16 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -909,7 +911,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (!*state) {
         *state = new WavefrontState();
         for (int i = 0; i < 64; i++) { WF_TRY(hipEventCreate(&(*state)->ev[i])); (*state)->n_ev = i + 1; }
-        WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 8 * 32 * sizeof(uint32_t)));
+        WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 16 * 32 * sizeof(uint32_t)));
         hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
         (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
@@ -973,7 +975,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             else hipLaunchKernelGGL(k_wf_shade<false>, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
             in_q ^= 1;
             if (sort_bits) {   /* order the two ray queues the next traces read (needs their lengths on the host: one small read-back) */
-                WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 WF_TRY(hipStreamSynchronize(stream));
                 polled = true;
                 const size_t n = st->cap_paths;                        /* scratch: q_sorted is free until the next classify */
@@ -984,10 +986,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             }
             if (it >= P.max_depth || polled) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
                 if (!polled) {
-                    WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 8 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     WF_TRY(hipStreamSynchronize(stream));
                 }
-                if (it >= P.max_depth && count && knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] wave steps so far: node %u leaf %u\n", st->host_counters[CTR(6)], st->host_counters[CTR(7)]);
+                if (it >= P.max_depth && count && knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] wave steps so far: node %u leaf %u; lanes during node steps (x64): idle %u waiting-with-leaf %u\n", st->host_counters[CTR(6)], st->host_counters[CTR(7)], st->host_counters[CTR(8)], st->host_counters[CTR(9)]);
                 if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
             }
         }
