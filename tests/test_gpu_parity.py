@@ -291,6 +291,24 @@ def test_config5_full_size(gpu, orc_det):
     assert whole.pixels[..., 3].min() >= 1.0
 
 
+def test_ray_queue_sort_changes_nothing(gpu, monkeypatch):
+    """The wavefront pipeline sorts its secondary-ray queues for coherence; the order rays are traced in must not change
+    a single bit of the film or a single counter: same render with the sort disabled."""
+    make = lambda be: scenes.instanced_cubes(be, n_copies=27, res=(160, 160), env_n=32)     # > 16 K rays per bounce, so the sort really runs
+    b, cam, res = make(gpu)
+    sc = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    films, stats = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FTN_WF_SORT", flag)
+        f = Film(gpu, res)
+        stats.append(si.render_parallel(sc, f, RandomSampler(2, 0, indexed=True), pipeline=WAVE, count_traffic=True))
+        films.append(f.pixels)
+    assert np.array_equal(bits(films[0]), bits(films[1]))
+    for k in ("rays_closest", "rays_any", "nodes_visited", "prims_tested", "camera_samples"):
+        assert stats[0][k] == stats[1][k], k
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_specular_glass_reports_unsupported(gpu):
     b = SceneBuilder(gpu)
