@@ -204,6 +204,10 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     uint32_t w_node_steps = 0, w_leaf_steps = 0;   /* COUNT only: wave-level step counts -> SIMD lane utilisation (FTN_WF_DEBUG) */
     uint32_t mode = TM_IDLE;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
+    /* The queue is cut into 8 contiguous slices, one per XCD (workgroups b and b + 8 share an XCD and therefore an L2): with the
+     * queue sorted by origin cell, an XCD's L2 only has to hold the part of the BVH its slice of space reaches.  A wave whose slice
+     * has run dry moves on to the next one, so the partition costs no load balance. */
+    uint32_t slice = blockIdx.x & 7u, slices_done = 0;
     /* per-wave chunk: few queue-head atomics, but small enough that the tail spreads over all waves */
     { uint32_t c = count / (gridDim.x * 4u * 16u); c &= ~63u; chunk = c < 64u ? 64u : (c > chunk ? chunk : c); }
     uint32_t rid = 0, cur = 0 /* byte offset of the node record */, neg16 = 0, lp = 0, lp_end = 0;
@@ -215,13 +219,13 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         const unsigned long long idle = __ballot(mode == TM_IDLE);
         if (!exhausted && (uint32_t)__popcll(idle) >= refill) {
             const uint32_t need = (uint32_t)__popcll(idle);
-            if (chunk_next == chunk_end) {                       /* the wave's chunk is used up: take a new one */
+            while (chunk_next == chunk_end && !exhausted) {      /* the wave's chunk is used up: take a new one from the current slice */
+                const uint32_t s_lo = (uint32_t)(((unsigned long long)count * slice) >> 3) & ~63u, s_hi = slice == 7u ? count : ((uint32_t)(((unsigned long long)count * (slice + 1u)) >> 3) & ~63u);
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, chunk);
-                base = __shfl(base, 0, 64);
-                chunk_next = base; chunk_end = base + chunk;
-                if (chunk_next >= count) { exhausted = true; chunk_end = chunk_next; }
-                else if (chunk_end > count) chunk_end = count;
+                if (lane == 0) base = atomicAdd(head + CTR(slice), chunk);
+                base = __shfl(base, 0, 64) + s_lo;
+                if (base >= s_hi) { slice = (slice + 1u) & 7u; if (++slices_done == 8u) exhausted = true; }   /* this slice is empty: help the next XCD's */
+                else { chunk_next = base; chunk_end = base + chunk < s_hi ? base + chunk : s_hi; }
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -732,11 +736,12 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
 __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {                                                                         /* new pass: generate fills both queues densely */
-        for (int i = 0; i < 16; i++) W.counters[CTR(i)] = 0;
+        for (int i = 0; i < 32; i++) W.counters[CTR(i)] = 0;
         W.counters[CTR(0)] = W.samples * W.valid_per_sample; W.counters[CTR(2)] = W.samples * W.valid_per_sample;
         stats->camera_samples += (unsigned long long)W.samples * W.valid_per_sample;
     } else if (mode == 1) {                                                                  /* before shade */
-        W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(4)] = 0; W.counters[CTR(5)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0;
+        W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0;
+        for (int i = 16; i < 32; i++) W.counters[CTR(i)] = 0;                                /* the per-XCD queue heads of the two trace kernels */
     } else if (mode == 2) {                                                                  /* before classify */
         for (int i = 0; i < WF_NCLASS; i++) W.cls[CTR(i)] = 0;
     }
@@ -856,7 +861,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.counters, 16 * 32))) return rc;
+        (rc = wf_alloc(st, &W.counters, 32 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -958,12 +963,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
             if (ev_used + 2 > 64) { rc = flush_events(); if (rc) return rc; }
             WF_TRY(hipEventRecord(st->ev[ev_used], stream));
-            launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(4)], 2 * W.n_paths);
+            launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (W.n_paths + 255) / 256);
-                launch_trace(true, count, spheres, sg, st->n_cu, lds, stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(5)], W.n_paths);
+                launch_trace(true, count, spheres, sg, st->n_cu, lds, stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], W.n_paths);
             }
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
