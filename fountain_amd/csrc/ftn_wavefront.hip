@@ -866,11 +866,13 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     return FTN_OK;
 }
 
+static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(name); return v ? (uint32_t)atoi(v) : def; }
+
 /* sorts queue[0, cnt) by the rays' coherence keys into `out`; *sorted_q = out (or the queue itself when it is too short to bother) */
 static int sort_ray_queue(WavefrontState* st, const RenderParams& P, const WfBuffers& W, bool any, uint32_t* queue, uint32_t cnt, uint32_t* out,
                           uint32_t* k_in, uint32_t* k_out, uint32_t bits, hipStream_t stream, const uint32_t** sorted_q) {
     *sorted_q = queue;
-    if (cnt < 16384u) return FTN_OK;
+    if (cnt < knob("FTN_WF_SORT_MIN", 16384u)) return FTN_OK;             /* short queues: the launch overhead of the sort outweighs its gain */
     if (any) hipLaunchKernelGGL(k_wf_ray_keys<true>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, queue, cnt, k_in, bits);
     else hipLaunchKernelGGL(k_wf_ray_keys<false>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, queue, cnt, k_in, bits);
     const int end_bit = (int)(3 * bits + 3);
@@ -883,7 +885,6 @@ static int sort_ray_queue(WavefrontState* st, const RenderParams& P, const WfBuf
 }
 
 /* tuning knobs of k_wf_trace (env overrides are for experiments only) */
-static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(name); return v ? (uint32_t)atoi(v) : def; }
 
 static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int n_cu, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
