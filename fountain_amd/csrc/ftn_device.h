@@ -72,7 +72,8 @@ struct DScene {
     uint32_t root_is_leaf, n_fat;
     /* textures (NULL / 0 when every material parameter is a constant): see ftn_texture.h */
     const ftn_texture* textures; const ftn_material_textures* mtex; const DImage* images; const float4* texels;
-    uint32_t n_textures, _pad2;
+    uint32_t n_textures;
+    uint32_t material_types;                /* bit t set: some material has ftn_material.type == t */
 };
 
 struct DCamera {
@@ -675,6 +676,8 @@ __device__ inline void add_lobe(DBsdf* B, const DLobe& L) { if (B->n == 0) B->lo
 __device__ inline DLobe mk_lobe(uint32_t kind, Rgb r, uint32_t fresnel, float p0, float p1, float ei, float et, const ftn_material* m) {
     DLobe L; L.kind = kind; L.fresnel = fresnel; L.r = r; L.p0 = p0; L.p1 = p1; L.ei = ei; L.et = et; L.m = m; return L;
 }
+/* MT >= 0: the material type is known at compile time (material-specialised shade kernels): the other cases fold away */
+template <int MT = -1>
 __device__ inline bool make_bsdf(const ftn_material& m, const DSI& si, bool allow_multiple_lobes, DBsdf* B) {
     B->ns = si.shading_n; B->ng = si.hit.n;
     B->ss = normalize(si.s_dpdu);
@@ -682,7 +685,7 @@ __device__ inline bool make_bsdf(const ftn_material& m, const DSI& si, bool allo
     B->n = 0;
     B->lobe[0] = mk_lobe(BX_LAMBERT, Rgb(0.0f), FR_NOOP, 0.0f, 0.0f, 1.0f, 1.0f, &m); B->lobe[1] = B->lobe[0];
     const Rgb a(m.a[0], m.a[1], m.a[2]), b(m.b[0], m.b[1], m.b[2]);
-    switch (m.type) {
+    switch (MT >= 0 ? (uint32_t)MT : m.type) {
         case FTN_MAT_MATTE: {                                  /* matte.rs:35-52; OrenNayar A/B precomputed in s1/s2 */
             Rgb r = clamp_positive(a);
             if (!r.is_black()) add_lobe(B, mk_lobe(m.s0 == 0.0f ? BX_LAMBERT : BX_OREN, r, FR_NOOP, m.s1, m.s2, 1.0f, 1.0f, &m));

@@ -673,6 +673,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
     sc->stack_entries = std::max<uint32_t>(hs.max_depth, 1u);
+    for (const ftn_material& m : mats) if (m.type < 32u) D.material_types |= 1u << m.type;
     if ((rc = sc->stats.alloc_zero(1))) return rc;
     if (has_tex) {                                               /* textures + MIP pyramids */
         const int nt = (int)d->n_textures, ni = d->images ? (int)d->n_images : 0;

@@ -546,14 +546,17 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 #ifndef FTN_SHADE_MIN_WAVES
 #define FTN_SHADE_MIN_WAVES 1
 #endif
-template <bool TEX>
-__global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderParams P, WfBuffers W, int in_q) {
+/* MT: -1 = every class in `class_mask`, material type read at run time (textured scenes);  0..4 = ONE material class, its BSDF code
+ * specialised at compile time (fewer registers: 3 waves/SIMD instead of 2, 4 for mirrors);  -2 = the classes without a BSDF
+ * (finished paths, misses / depth limit, null materials), the material branch compiled out. */
+template <bool TEX, int MT>
+__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : 3))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask) {
     const DScene& S = P.S;
-    /* virtual, 256-aligned concatenation of the class segments: a workgroup never straddles two classes */
+    /* virtual, 256-aligned concatenation of the selected class segments: a workgroup never straddles two classes */
     uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
     cbase[0] = 0;
 #pragma unroll
-    for (int k = 0; k < WF_NCLASS; k++) { ccnt[k] = W.cls[CTR(k)]; cbase[k + 1] = cbase[k] + ((ccnt[k] + 255u) & ~255u); }
+    for (int k = 0; k < WF_NCLASS; k++) { ccnt[k] = ((class_mask >> k) & 1u) ? W.cls[CTR(k)] : 0u; cbase[k + 1] = cbase[k] + ((ccnt[k] + 255u) & ~255u); }
     const uint32_t count = cbase[WF_NCLASS];
     uint32_t* out_q = W.q_active[in_q ^ 1];
     uint32_t* out_count = &W.counters[CTR(in_q == 0 ? 1 : 0)];
@@ -625,7 +628,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                 else {
                     Rng rng; { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
                     const int mat = (int)S.prim_info[2 * si.prim].x;
-                    if (mat < 0) {
+                    if (MT == -2 || mat < 0) {
                         DRay nr = spawn_ray(si.hit, ray0.d);                       /* null bsdf: path.rs:77-81 */
                         W.ray[2 * (size_t)(p)] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray[2 * (size_t)(p) + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
                         push_closest = true;
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(256, FTN_SHADE_MIN_WAVES) k_wf_shade(RenderPar
                             const DTexDiffs td = compute_tex_diffs(si.hit.p, si.hit.n, ex.dpdu, ex.dpdv, rd);
                             mloc = material_resolve(S, mat, ex.uv, td); mp = &mloc;
                         }
-                        if (!make_bsdf(*mp, si, true, &B)) { err = FTN_ERR_UNSUPPORTED; alive = false; }
+                        if (!make_bsdf<(MT >= 0 ? MT : -1)>(*mp, si, true, &B)) { err = FTN_ERR_UNSUPPORTED; alive = false; }
                         else {
                             if (bsdf_num(B, T_ALL & ~T_SPECULAR) > 0 && S.n_lights > 0) {
                                 /* uniform_sample_one_light + first half of estimate_direct (integrator/mod.rs:289-329) */
@@ -977,8 +980,19 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
             }
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
-            if (P.S.n_textures != 0) hipLaunchKernelGGL(k_wf_shade<true>, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
-            else hipLaunchKernelGGL(k_wf_shade<false>, dim3(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q);
+            {
+                const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));
+                if (P.S.n_textures != 0) hipLaunchKernelGGL((k_wf_shade<true, -1>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                else if (!knob("FTN_SHADE_SPECIALISE", 1)) hipLaunchKernelGGL((k_wf_shade<false, -1>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                else {   /* one launch per material type present in the scene + one for the classes without a BSDF */
+                    hipLaunchKernelGGL((k_wf_shade<false, -2>), sgrid, dim3(256), 0, stream, P, W, in_q, 0x83u);
+                    if (P.S.material_types & 1u) hipLaunchKernelGGL((k_wf_shade<false, 0>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 2);
+                    if (P.S.material_types & 2u) hipLaunchKernelGGL((k_wf_shade<false, 1>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 3);
+                    if (P.S.material_types & 4u) hipLaunchKernelGGL((k_wf_shade<false, 2>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 4);
+                    if (P.S.material_types & 8u) hipLaunchKernelGGL((k_wf_shade<false, 3>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 5);
+                    if (P.S.material_types & 16u) hipLaunchKernelGGL((k_wf_shade<false, 4>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 6);
+                }
+            }
             in_q ^= 1;
             if (sort_bits) {   /* order the two ray queues the next traces read (needs their lengths on the host: one small read-back) */
                 WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
