@@ -36,3 +36,23 @@ def test_tile_shard_partition():
         first, stride, _ = tile_shard(r, 8)
         seen[first::stride] += 1
     assert (seen == 1).all() and max(len(range(r, n, 8)) for r in range(8)) == 1020
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gpu_render_processes(tmp_path, world):
+    """The product itself under torch.distributed: `world` processes (sharing this box's one GPU) render interleaved tile shards with
+    ftn_render_device into device films and merge them with the frame's single reduce; the result equals the unsharded render."""
+    out = str(tmp_path / "merged_gpu.npz")
+    port = 29700 + (os.getpid() + world) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    assert int(d["world"]) == world and np.array_equal(d["rays"], d["rays_whole"])
+    merged, whole = d["merged"], d["whole"]
+    diff = (merged.view(np.uint32) != whole.view(np.uint32)).any(axis=-1)
+    assert int(diff.sum()) <= 4 * int(d["spill"])              # a spill pixel's two addends may arrive in the other order
+    assert np.allclose(merged, whole, rtol=2e-6, atol=1e-7) and merged[..., 3].min() >= 2.0
