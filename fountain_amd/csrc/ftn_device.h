@@ -45,7 +45,7 @@ struct DLight {
     float world_center[3]; float world_radius; float area;
     /* infinite */
     uint32_t env_w, env_h;
-    const float* texels;                    /* env_w*env_h*3 */
+    const float4* texels;                   /* env_w*env_h texels, rgb + pad: one aligned 16-byte load each */
     const float* cond_func;                 /* [nv][nu]   */
     const float* cond_cdf;                  /* [nv][nu+1] */
     const float* cond_integral;             /* [nv]       */
@@ -783,8 +783,8 @@ __device__ inline bool bsdf_sample(const DBsdf& B, V3 wo_w, V2 u, uint32_t flags
 __host__ __device__ inline Rgb env_texel(const DLight& L, int s, int t) {
     int w = (int)L.env_w, h = (int)L.env_h;
     s = ((s % w) + w) % w; t = ((t % h) + h) % h;
-    const float* p = L.texels + ((size_t)t * w + s) * 3;
-    return Rgb(p[0], p[1], p[2]);
+    const float4 p = L.texels[(size_t)t * w + s];
+    return Rgb(p.x, p.y, p.z);
 }
 __host__ __device__ inline Rgb env_lookup(const DLight& L, V2 st) {      /* triangle(0, st): mipmap.rs:258-272 */
     float s = st.x * (float)L.env_w - 0.5f, t = st.y * (float)L.env_h - 0.5f;

@@ -510,7 +510,7 @@ struct ftn_scene {
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
     DevBuf<float4> nodes, geom, fat; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
-    DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc;
+    DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
     DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
@@ -519,6 +519,7 @@ struct ftn_scene {
     ~ftn_scene() {
         nodes.release(); geom.release(); fat.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
+        for (auto& b : misc4) b.release();
         textures.release(); mtex.release(); images.release(); texels.release();
         accA.release(); accB.release(); accC.release(); tiles.release(); stats.release();
         wavefront_destroy(wf);
@@ -637,7 +638,9 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             L.env_w = e.width; L.env_h = e.height;
             /* compute_distribution infinite.rs:63-78: (height, width) = resolution() name swap, square maps only; level = 0 exactly */
             const uint32_t height = e.width, width = e.height;
-            DLight hostL = L; hostL.texels = e.texels;
+            std::vector<float4> tex4((size_t)e.width * e.height);
+            for (size_t k = 0; k < tex4.size(); k++) tex4[k] = make_float4(e.texels[3 * k], e.texels[3 * k + 1], e.texels[3 * k + 2], 0.0f);
+            DLight hostL = L; hostL.texels = tex4.data();
             std::vector<float> img((size_t)width * height);
             for (uint32_t j = 0; j < height; j++) {
                 float v = (float)j / (float)height;
@@ -653,15 +656,15 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             for (uint32_t v2 = 0; v2 < nv; v2++) cint[v2] = dist1d_build(&img[(size_t)v2 * nu], nu, &ccdf[(size_t)v2 * (nu + 1)]);
             float mint = dist1d_build(cint.data(), nv, mcdf.data());
             L.nu = nu; L.nv = nv; L.marg_integral = mint;
-            DevBuf<float> b0, b1, b2, b3, b4, b5;
-            if ((rc = b0.upload(e.texels, (size_t)e.width * e.height * 3))) return rc;
+            DevBuf<float4> b0; DevBuf<float> b1, b2, b3, b4, b5;
+            if ((rc = b0.upload(tex4.data(), tex4.size()))) return rc;
             if ((rc = b1.upload(img.data(), img.size()))) return rc;
             if ((rc = b2.upload(ccdf.data(), ccdf.size()))) return rc;
             if ((rc = b3.upload(cint.data(), cint.size()))) return rc;
             if ((rc = b4.upload(cint.data(), cint.size()))) return rc;             /* marginal func == conditional integrals */
             if ((rc = b5.upload(mcdf.data(), mcdf.size()))) return rc;
             L.texels = b0.p; L.cond_func = b1.p; L.cond_cdf = b2.p; L.cond_integral = b3.p; L.marg_func = b4.p; L.marg_cdf = b5.p;
-            sc->misc.push_back(b0); sc->misc.push_back(b1); sc->misc.push_back(b2); sc->misc.push_back(b3); sc->misc.push_back(b4); sc->misc.push_back(b5);
+            sc->misc4.push_back(b0); sc->misc.push_back(b1); sc->misc.push_back(b2); sc->misc.push_back(b3); sc->misc.push_back(b4); sc->misc.push_back(b5);
         }
     }
     if ((rc = sc->lights.upload(lights.data(), lights.size()))) return rc;
