@@ -2,7 +2,9 @@
 (src/bin/render.rs:16-104) over the MI355X library -- parse the scene file, PathIntegrator::new(5, 1.0), render, write
 Film::into_spectrum_buffer as an OpenEXR file.
 
---threads of the reference has no meaning here; --gpu picks the HIP device.  --exact-stream renders with the reference's own
+--threads of the reference has no meaning here; --gpu picks the HIP device.  Started under `python -m torch.distributed.run
+--nproc-per-node N …` every rank renders the film tiles r, r+N, … on GPU LOCAL_RANK and the films are merged with the frame's single
+reduce (RCCL when every rank has its own GPU, gloo with --dist-backend gloo); rank 0 writes the image.  --exact-stream renders with the reference's own
 per-tile RandomSampler stream (one lane per 16x16 tile: for validation, slow); the default re-seeds per (pixel, sample) so that
 samples run in parallel (samplers).
 """
@@ -23,7 +25,12 @@ def main(argv=None):
     ap.add_argument("--exact-stream", action="store_true")
     ap.add_argument("--max-depth", type=int, default=5)          # render.rs:79 hard-codes PathIntegrator::new(5, 1.0)
     ap.add_argument("--rr-threshold", type=float, default=1.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     opts = ap.parse_args(argv)
+    import os
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        opts.gpu = int(os.environ.get("LOCAL_RANK", "0")) if opts.dist_backend == "nccl" else opts.gpu
 
     be = default_backend()
     parsed = PbrtScene(opts.scene_file, be)
@@ -37,10 +44,31 @@ def main(argv=None):
     info = scene.info()
     print("scene: %d primitives, %d BVH nodes, %d lights" % (info["n_prims"], info["n_nodes"], info["n_lights"]), file=sys.stderr)
     t0 = time.time()
-    st = integrator.render_parallel(scene, film, sampler, device=opts.gpu)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from .distributed import merge_film, tile_shard
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if opts.dist_backend == "nccl":
+            torch.cuda.set_device(opts.gpu)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", opts.gpu))
+        else:
+            dist.init_process_group("gloo")
+        st = integrator.render_parallel(scene, film, sampler, tiles=tile_shard(rank, world), device=opts.gpu)
+        t = torch.from_numpy(film.pixels)
+        if opts.dist_backend == "nccl":
+            t = t.cuda(opts.gpu)
+        merge_film(t)
+        film.pixels[...] = t.cpu().numpy()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return 0
+    else:
+        st = integrator.render_parallel(scene, film, sampler, device=opts.gpu)
     dt = time.time() - t0
     rays = st["rays_closest"] + st["rays_any"]
-    print("Completed rendering in %.3f s (%.1f Mrays/s)" % (dt, rays / dt / 1e6), file=sys.stderr)
+    print("Completed rendering in %.3f s (%.1f Mrays/s%s)" % (dt, rays / dt / 1e6, " on rank 0 of %d" % world if world > 1 else ""), file=sys.stderr)
     img, (w, h) = film.into_spectrum_buffer()
     write_exr(filename, img, be)
     return 0

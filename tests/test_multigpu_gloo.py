@@ -56,3 +56,22 @@ def test_sharded_gpu_render_processes(tmp_path, world):
     diff = (merged.view(np.uint32) != whole.view(np.uint32)).any(axis=-1)
     assert int(diff.sum()) <= 4 * int(d["spill"])              # a spill pixel's two addends may arrive in the other order
     assert np.allclose(merged, whole, rtol=2e-6, atol=1e-7) and merged[..., 3].min() >= 2.0
+
+
+@pytest.mark.gpu
+def test_render_cli_under_torchrun(tmp_path):
+    """`python -m fountain_amd.render` started as a 2-rank job (both ranks on this box's GPU, films merged over gloo) writes the
+    same image as the single-process run."""
+    from fountain_amd import default_backend, read_exr
+    golden = os.path.join(ROOT, "tests", "golden", "cornell.pbrt")
+    one, two = str(tmp_path / "one.exr"), str(tmp_path / "two.exr")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "fountain_amd.render", golden, "-o", one, "--samples", "4"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    port = 29900 + os.getpid() % 90
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        "-m", "fountain_amd.render", golden, "-o", two, "--samples", "4", "--dist-backend", "gloo"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    be = default_backend()
+    a, b = read_exr(one, be), read_exr(two, be)
+    assert a.shape == (64, 64, 3) and np.allclose(a, b, rtol=2e-6, atol=1e-7) and (a != b).mean() < 0.01 and a.mean() > 0.05
