@@ -65,10 +65,13 @@ int orc_camera_perspective(const ftn_transform* c2w, const int32_t res[2], const
 }
 int orc_film_init(const int32_t res[2], const float cw[4], ftn_film_desc* out) { make_film(res, cw, out); return 0; }
 int orc_film_sample_bounds(const ftn_film_desc* f, int32_t out[4]) { Film film; film.init(f); Bounds2i b = film.sample_bounds(); out[0] = b.x0; out[1] = b.y0; out[2] = b.x1; out[3] = b.y1; return 0; }
-static void list_tiles(const Film& film, std::vector<Bounds2i>* tiles, Bounds2i* sb_out) {   // Bounds2i::iter_tiles(16), bounds.rs:85-97
+static void iter_tiles(Bounds2i b, int tile_size, std::vector<Bounds2i>* tiles) {            // Bounds2i::iter_tiles, bounds.rs:85-97
+    for (int y = b.y0; y < b.y1; y += tile_size) for (int x = b.x0; x < b.x1; x += tile_size)
+        tiles->push_back(Bounds2i{x, y, std::min(x + tile_size, b.x1), std::min(y + tile_size, b.y1)});
+}
+static void list_tiles(const Film& film, std::vector<Bounds2i>* tiles, Bounds2i* sb_out) {   // render_parallel: sample_bounds.iter_tiles(16), integrator/mod.rs:218-227
     Bounds2i sb = film.sample_bounds(); *sb_out = sb;
-    for (int y = sb.y0; y < sb.y1; y += 16) for (int x = sb.x0; x < sb.x1; x += 16)
-        tiles->push_back(Bounds2i{x, y, std::min(x + 16, sb.x1), std::min(y + 16, sb.y1)});
+    iter_tiles(sb, 16, tiles);
 }
 int orc_film_tile_count(const ftn_film_desc* f, uint32_t* out) { Film film; film.init(f); std::vector<Bounds2i> t; Bounds2i sb; list_tiles(film, &t, &sb); *out = (uint32_t)t.size(); return 0; }
 int orc_film_resolve(const ftn_pixel* p, size_t n, float* rgb) { film_resolve(p, n, rgb); return 0; }
@@ -276,6 +279,17 @@ float orc_kat_math(int which, float x, float y) {
                      case 4: return m_atan(x); case 5: return m_atan2(x, y); case 6: return m_ln(x); case 7: return m_log2(x); default: return 0.0f; }
 }
 float orc_kat_roughness_to_alpha(float r) { return roughness_to_alpha(r); }
+// Bounds2i::iter_points / iter_tiles (bounds.rs:76-97): out holds 2 ints per point / 4 per tile; returns the count
+size_t orc_kat_iter_points(const int32_t b[4], int32_t* out, size_t cap) {
+    size_t n = 0;
+    for (int y = b[1]; y < b[3]; y++) for (int x = b[0]; x < b[2]; x++) { if (n < cap) { out[2 * n] = x; out[2 * n + 1] = y; } n++; }
+    return n;
+}
+size_t orc_kat_iter_tiles(const int32_t b[4], int32_t tile_size, int32_t* out, size_t cap) {
+    std::vector<Bounds2i> t; iter_tiles(Bounds2i{b[0], b[1], b[2], b[3]}, tile_size, &t);
+    for (size_t i = 0; i < t.size() && i < cap; i++) { out[4 * i] = t[i].x0; out[4 * i + 1] = t[i].y0; out[4 * i + 2] = t[i].x1; out[4 * i + 3] = t[i].y1; }
+    return t.size();
+}
 // ---- textures (orc_texture.hpp)
 // a level of the pyramid MIPMap::new builds (mipmap.rs:78-145)
 int orc_test_mipmap_level(uint32_t w, uint32_t h, const float* texels, uint32_t level, uint32_t* lw, uint32_t* lh, float* rgb_out) {

@@ -215,3 +215,28 @@ def test_next_float_quirks(o):
     assert f32(up(-1.0)) == np.nextafter(f32(-1), f32(0)) and f32(up(-0.0)) == f32(1e-45)
     assert np.isnan(dn(0.0))                      # bits(-0.0) - 1 = 0x7fffffff
     assert up(np.inf) == np.inf and dn(-np.inf) == -np.inf
+
+
+def test_bounds_iter_points_and_tiles(o):
+    """bounds.rs:257-290 (test_bounds_iter, test_bounds_iter_tiles): x runs fastest; tiles are clipped to the bounds and their
+    areas add up to the bounds' area for tile sizes that do not divide it; the product's film tiling agrees (ftn_film_tile_count)."""
+    import ctypes as C
+    lib = o.lib
+    lib.orc_kat_iter_points.restype = C.c_size_t
+    lib.orc_kat_iter_points.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.orc_kat_iter_tiles.restype = C.c_size_t
+    lib.orc_kat_iter_tiles.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]
+    b = np.array([-1, -2, 1, 1], np.int32)
+    out = np.zeros((16, 2), np.int32)
+    n = lib.orc_kat_iter_points(b.ctypes.data, out.ctypes.data, 16)
+    assert [tuple(p) for p in out[:n]] == [(-1, -2), (0, -2), (-1, -1), (0, -1), (-1, 0), (0, 0)]
+    small = np.array([0, 0, 2, 2], np.int32)
+    tiles = np.zeros((8, 4), np.int32)
+    n = lib.orc_kat_iter_tiles(small.ctypes.data, 1, tiles.ctypes.data, 8)
+    assert [tuple(t) for t in tiles[:n]] == [(0, 0, 1, 1), (1, 0, 2, 1), (0, 1, 1, 2), (1, 1, 2, 2)]
+    big = np.array([0, 0, 100, 100], np.int32)
+    for ts in (1, 5, 7, 16):
+        buf = np.zeros((10000, 4), np.int32)
+        n = lib.orc_kat_iter_tiles(big.ctypes.data, ts, buf.ctypes.data, 10000)
+        t = buf[:n]
+        assert int(((t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])).sum()) == 100 * 100
