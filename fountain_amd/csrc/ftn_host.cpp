@@ -366,6 +366,27 @@ static Aabb prim_bounds(const ftn_scene_desc* d, const ftn_prim& p) {
 }
 static int validate_desc(const ftn_scene_desc* d) {
     if (!d) return fail(FTN_ERR_INVALID_ARGUMENT, "null scene description");
+    if ((d->n_prims && !d->prims) || (d->n_triangles && (!d->tri_indices || !d->tri_mesh)) || (d->n_vertices && !d->P) || (d->n_meshes && !d->meshes) ||
+        (d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_area_emit && !d->area_emit) || (d->n_lights && !d->lights) || (d->n_envmaps && !d->envmaps))
+        return fail(FTN_ERR_INVALID_ARGUMENT, "a count is non-zero but its array is NULL");
+    for (uint32_t i = 0; i < d->n_materials; i++) if (d->materials[i].type > FTN_MAT_GLASS) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown material type");
+    for (uint32_t i = 0; i < d->n_meshes; i++) {
+        if (d->meshes[i].has_normals && !d->N) return fail(FTN_ERR_INVALID_ARGUMENT, "a mesh has normals but N is NULL");
+        if (d->meshes[i].has_uvs && !d->UV) return fail(FTN_ERR_INVALID_ARGUMENT, "a mesh has uvs but UV is NULL");
+    }
+    for (uint32_t i = 0; i < d->n_envmaps; i++) if (!d->envmaps[i].texels) return fail(FTN_ERR_INVALID_ARGUMENT, "environment map without texels");
+    if (d->n_textures && d->textures) {                        /* textures */
+        const int nt = (int)d->n_textures, ni = d->images ? (int)d->n_images : 0;
+        for (int i = 0; i < nt; i++) {
+            const ftn_texture& t = d->textures[i];
+            if (t.kind > FTN_TEX_IMAGE) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown texture kind");
+            if (t.kind == FTN_TEX_CHECKERBOARD && (t.tex1 < 0 || t.tex1 >= nt || t.tex2 < 0 || t.tex2 >= nt)) return fail(FTN_ERR_INVALID_ARGUMENT, "checkerboard child texture out of range");
+            if (t.kind == FTN_TEX_IMAGE && (t.image < 0 || t.image >= ni)) return fail(FTN_ERR_INVALID_ARGUMENT, "image index out of range");
+        }
+        for (int i = 0; i < ni; i++) { const ftn_image& im = d->images[i]; if (im.width == 0 || im.height == 0 || !im.texels || im.wrap > FTN_WRAP_CLAMP) return fail(FTN_ERR_INVALID_ARGUMENT, "bad image"); }
+        if (d->material_textures) for (uint32_t i = 0; i < d->n_materials; i++) { const ftn_material_textures& mt = d->material_textures[i];
+            for (int32_t id : {mt.a, mt.b, mt.s0, mt.s1, mt.s2}) if (id >= nt) return fail(FTN_ERR_INVALID_ARGUMENT, "material texture index out of range"); }
+    }
     for (uint32_t i = 0; i < d->n_triangles; i++) {
         if (d->tri_mesh[i] >= d->n_meshes) return fail(FTN_ERR_INVALID_ARGUMENT, "triangle mesh id out of range");
         for (int k = 0; k < 3; k++) if (d->tri_indices[3 * (size_t)i + k] >= d->n_vertices) return fail(FTN_ERR_INVALID_ARGUMENT, "vertex index out of range");
