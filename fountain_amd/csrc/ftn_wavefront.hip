@@ -3,17 +3,20 @@
  *
  * The reference walks one path at a time: intersect -> emission -> NEE (shadow ray + MIS ray) -> BSDF sample -> RR -> loop.
  * Here a PASS renders S samples of every owned pixel at once; paths live as float4 SoA records in HBM and every bounce runs
- * three kernels over queues of path ids:
+ * these kernels over queues of path / ray ids:
  *
  *   k_wf_generate   get_camera_sample + generate_ray (sampler/mod.rs:43-51, camera/mod.rs:145-205); all paths -> closest queue
  *   k_wf_trace<ANY> Scene::intersect / intersect_test (bvh.rs:160-266) for a queue of rays.  Persistent 256-thread
- *                   workgroups; each wave64 pulls rays from the queue with ONE atomic per refill (__ballot / __popcll /
- *                   __shfl): lanes whose ray finished are re-armed while the others keep walking, so a wave stays full
- *                   until the queue is drained.  Per-lane node stack in LDS, [level][lane] interleaved.
- *   k_wf_shade      everything between two intersect calls of the Li loop: resolves the previous bounce's direct lighting
+ *                   workgroups; each wave64 pulls rays from the queue in chunks (one atomic per chunk) and re-arms idle lanes
+ *                   by __ballot / __popcll ranks: lanes whose ray finished get a new one while the others keep walking.
+ *                   Per-lane node stack in LDS, [level][lane] interleaved.  The queue is cut into one slice per XCD.
+ *   k_wf_classify   groups the active paths by shading class (finished / missed / one per material type / null material)
+ *   k_wf_shade<MT>  everything between two intersect calls of the Li loop: resolves the previous bounce's direct lighting
  *                   (shadow + MIS results), emission, termination, Material -> Bsdf, uniform_sample_one_light /
  *                   estimate_direct set-up, BSDF sampling, Russian roulette; emits shadow / MIS / continuation rays and
- *                   compacts the surviving paths into the next queue (ballot + one atomic per wave).
+ *                   compacts the surviving paths into the next queue (one atomic per workgroup and queue).  One launch per
+ *                   material type present, BSDF code specialised at compile time.
+ *   k_wf_ray_keys + rocPRIM radix sort: orders the two ray queues by Morton(origin cell) | direction octant (coherence)
  *   k_wf_accumulate Film::add_sample_to_tile for the pass's samples of each pixel IN SAMPLE ORDER (film.rs:136-172).
  *
  * All per-path arithmetic and the order of the RNG draws are those of the reference (and of the megakernel), so both
