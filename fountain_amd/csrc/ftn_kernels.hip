@@ -6,8 +6,10 @@
  *                   (src/integrator/path.rs:25-95) or DirectLightingIntegrator (src/integrator/direct_lighting.rs:50-110)
  *                   inlined.  One 256-thread workgroup = one 16x16 film tile (4 wave64).
  *                     FTN_SAMPLER_INDEXED    : one lane per pixel, samples in order, film sums kept in registers;
- *                     FTN_SAMPLER_TILE_SERIAL: lane 0 of the workgroup walks the tile serially, exactly like the
- *                                              reference's per-tile RandomSampler stream (validation only).
+ *   k_render_serial FTN_SAMPLER_TILE_SERIAL: the reference's per-tile RandomSampler stream is serial by construction (one
+ *                   Xoshiro256+ state per 16x16 tile, a path-dependent number of draws per sample), so ONE LANE walks a whole
+ *                   tile exactly like render_tile does and the tiles of the film are the parallel dimension (a 4096^2 film has
+ *                   65 536 of them).
  *   k_trace_batch   Scene::intersect / intersect_test for arrays of rays (src/scene/mod.rs:51-57).
  *   k_film_resolve  Film::merge_film_tile (src/film.rs:121-132) from the three accumulators into Pixel{xyz,w}.
  *
@@ -334,7 +336,20 @@ __global__ void __launch_bounds__(256) k_render_mega(RenderParams P) {
             }
             if (in_crop) P.accA[ai] = acc;
         }
-    } else if (threadIdx.x == 0) {
+    }
+    flush_counters(P.stats, lc, COUNT);
+    if (err) atomicCAS(&P.stats->error, 0, err);
+}
+
+template <bool COUNT, bool TEX>
+__global__ void __launch_bounds__(256) k_render_serial(RenderParams P) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
+    LaneCounters lc; int err = 0;
+    Tracer<COUNT> T{P.S, LdsStack{lds_stack + threadIdx.x, 256u}, lc};
+    if (ti < P.n_tiles) {
+        const DTile tile = P.tiles[ti];
+        FilmCtx F; make_film_ctx(P, tile, &F);
         Rng rng; rng.seed(tile.tile_id);                 /* clone_with_seed(tile_id): random.rs:61-67 */
         float4 dummy = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int py = tile.y0; py < tile.y1; py++)
@@ -348,6 +363,14 @@ __global__ void __launch_bounds__(256) k_render_mega(RenderParams P) {
 
 void launch_render_mega(const RenderParams& p, bool count, hipStream_t stream) {
     if (p.n_tiles == 0) return;
+    if (p.sampler_kind != FTN_SAMPLER_INDEXED) {
+        const size_t lds_s = (size_t)p.stack_entries * 256 * sizeof(uint32_t);
+        const dim3 g((p.n_tiles + 255u) / 256u);
+        const bool tex_s = p.S.n_textures != 0;
+        if (tex_s) { if (count) hipLaunchKernelGGL((k_render_serial<true, true>), g, dim3(256), lds_s, stream, p); else hipLaunchKernelGGL((k_render_serial<false, true>), g, dim3(256), lds_s, stream, p); }
+        else { if (count) hipLaunchKernelGGL((k_render_serial<true, false>), g, dim3(256), lds_s, stream, p); else hipLaunchKernelGGL((k_render_serial<false, false>), g, dim3(256), lds_s, stream, p); }
+        return;
+    }
     size_t lds = (size_t)p.stack_entries * 256 * sizeof(uint32_t);
     const bool tex = p.S.n_textures != 0;
     if (tex) { if (count) hipLaunchKernelGGL((k_render_mega<true, true>), dim3(p.n_tiles), dim3(256), lds, stream, p); else hipLaunchKernelGGL((k_render_mega<false, true>), dim3(p.n_tiles), dim3(256), lds, stream, p); }
