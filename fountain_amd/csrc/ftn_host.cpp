@@ -804,7 +804,8 @@ static int trace_batch(const ftn_scene* cs, const float* rays, size_t n, int mod
     HIP_TRY(hipMemset(s->stats.p, 0, sizeof(DevStats)));
     hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, 0));
-    launch_trace_batch(s->d, d_rays.p, n, mode, d_t.p, d_p.p, d_b.p, d_occ.p, d_o.p, s->stats.p, s->stack_entries, st != nullptr, 0);
+    if (getenv("FTN_BATCH_SIMPLE")) launch_trace_batch(s->d, d_rays.p, n, mode, d_t.p, d_p.p, d_b.p, d_occ.p, d_o.p, s->stats.p, s->stack_entries, st != nullptr, 0);   /* one lane per ray, plain loop */
+    else if ((rc = wavefront_trace_batch(&s->wf, s->d, s->stack_entries, d_rays.p, n, mode, st != nullptr, d_t.p, d_p.p, d_b.p, d_occ.p, d_o.p, s->stats.p, 0))) { cleanup(); return fail(rc, wavefront_error()); }
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());

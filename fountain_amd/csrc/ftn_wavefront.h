@@ -11,6 +11,10 @@ namespace ftn {
 struct WavefrontState;
 struct WavefrontTimes { double trace_ms; unsigned long long trace_launches; };
 int wavefront_render(WavefrontState** state, const RenderParams& P, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times);
+/* Scene::intersect (mode 0: t / prim / barycentrics, mode 2: + full interaction in out24) and intersect_test (mode 1) for n rays of
+ * 8 floats {o, d, t_max, time} in DEVICE memory; outputs are device pointers (any may be NULL) */
+int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stack_entries, const float* d_rays8, size_t n, int mode, bool count,
+                          float* t_hit, int* prim, float* bary, unsigned char* occluded, float* out24, DevStats* stats, hipStream_t stream);
 void wavefront_destroy(WavefrontState* state);
 const char* wavefront_error();
 }  // namespace ftn

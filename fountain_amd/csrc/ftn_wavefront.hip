@@ -919,14 +919,84 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
 #undef FTN_TR
 }
 
-int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times) {
-    if (!*state) {
-        *state = new WavefrontState();
-        for (int i = 0; i < 64; i++) { WF_TRY(hipEventCreate(&(*state)->ev[i])); (*state)->n_ev = i + 1; }
-        WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 16 * 32 * sizeof(uint32_t)));
-        hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
-        (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+static int wf_state_init(WavefrontState** state) {
+    if (*state) return FTN_OK;
+    *state = new WavefrontState();
+    for (int i = 0; i < 64; i++) { WF_TRY(hipEventCreate(&(*state)->ev[i])); (*state)->n_ev = i + 1; }
+    WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 16 * 32 * sizeof(uint32_t)));
+    hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
+    (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return FTN_OK;
+}
+
+/* ------------------------------------------------------------------ Scene::intersect / intersect_test for arrays of rays (ftn_intersect*):
+ * the same traversal kernel (and coherence sort) the renderer uses, over a queue that simply lists the rays */
+__global__ void __launch_bounds__(256) k_batch_setup(const float* __restrict__ rays8, uint32_t n, float4* __restrict__ ray, uint32_t* __restrict__ queue) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays8 + 8 * (size_t)i;
+    ray[2 * (size_t)i] = make_float4(r[0], r[1], r[2], r[7]);            /* o, time */
+    ray[2 * (size_t)i + 1] = make_float4(r[3], r[4], r[5], r[6]);        /* d, t_max */
+    queue[i] = i;
+}
+__global__ void __launch_bounds__(256) k_batch_finish(DScene S, const float* __restrict__ rays8, uint32_t n, const float4* __restrict__ hit, const int* __restrict__ hit_prim,
+                                                      float* t_hit, int* prim, float* bary, float* out24) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 h4 = hit[i]; const int hp = hit_prim[i];
+    if (t_hit) t_hit[i] = hp >= 0 ? h4.x : FTN_INF;
+    if (prim) prim[i] = hp;
+    if (bary) { bary[3 * (size_t)i] = hp >= 0 ? h4.y : 0.0f; bary[3 * (size_t)i + 1] = hp >= 0 ? h4.z : 0.0f; bary[3 * (size_t)i + 2] = hp >= 0 ? h4.w : 0.0f; }
+    if (out24) {                                                        /* the full SurfaceInteraction of the hit (ftn_intersect_full) */
+        float* o = out24 + 24 * (size_t)i;
+        if (hp < 0) { for (int k = 0; k < 24; k++) o[k] = 0.0f; o[23] = -1.0f; }
+        else {
+            const float* r = rays8 + 8 * (size_t)i;
+            DRay ray0; ray0.o = V3(r[0], r[1], r[2]); ray0.d = V3(r[3], r[4], r[5]); ray0.t_max = r[6]; ray0.time = r[7];
+            DHit h; h.t = h4.x; h.b0 = h4.y; h.b1 = h4.z; h.b2 = h4.w; h.prim = hp;
+            DSI si; make_interaction(S, h, ray0, &si);
+            o[0] = si.hit.p.x; o[1] = si.hit.p.y; o[2] = si.hit.p.z; o[3] = si.hit.p_err.x; o[4] = si.hit.p_err.y; o[5] = si.hit.p_err.z;
+            o[6] = si.hit.n.x; o[7] = si.hit.n.y; o[8] = si.hit.n.z; o[9] = 0.0f; o[10] = 0.0f;
+            o[11] = si.wo.x; o[12] = si.wo.y; o[13] = si.wo.z; o[14] = si.s_dpdu.x; o[15] = si.s_dpdu.y; o[16] = si.s_dpdu.z;
+            o[17] = 0.0f; o[18] = 0.0f; o[19] = 0.0f; o[20] = si.shading_n.x; o[21] = si.shading_n.y; o[22] = si.shading_n.z; o[23] = h.t;
+        }
     }
+}
+int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stack_entries, const float* d_rays8, size_t n_rays, int mode, bool count,
+                          float* t_hit, int* prim, float* bary, unsigned char* occluded, float* out24, DevStats* stats, hipStream_t stream) {
+    if (n_rays == 0) return FTN_OK;
+    if (n_rays >= (1ull << 31)) { g_wf_err = "too many rays in one batch"; return FTN_ERR_INVALID_ARGUMENT; }
+    int rc = wf_state_init(state); if (rc) return rc;
+    WavefrontState* st = *state;
+    const uint32_t n = (uint32_t)n_rays;
+    const bool any = mode == 1;
+    float4 *ray = nullptr, *hit = nullptr; int* hit_prim = nullptr; uint32_t *queue = nullptr, *scratch = nullptr, *counters = nullptr;
+    auto cleanup = [&]() { (void)hipFree(ray); (void)hipFree(hit); (void)hipFree(hit_prim); (void)hipFree(queue); (void)hipFree(scratch); (void)hipFree(counters); };
+#define WFB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_wf_err = std::string(#expr ": ") + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE; } } while (0)
+    WFB_TRY(hipMalloc((void**)&ray, (size_t)n * 32)); WFB_TRY(hipMalloc((void**)&queue, (size_t)n * 4)); WFB_TRY(hipMalloc((void**)&scratch, (size_t)n * 12));
+    WFB_TRY(hipMalloc((void**)&counters, 32 * 32 * 4)); WFB_TRY(hipMemsetAsync(counters, 0, 32 * 32 * 4, stream));
+    if (!any) { WFB_TRY(hipMalloc((void**)&hit, (size_t)n * 16)); WFB_TRY(hipMalloc((void**)&hit_prim, (size_t)n * 4)); }
+    hipLaunchKernelGGL(k_batch_setup, dim3((n + 255) / 256), dim3(256), 0, stream, d_rays8, n, ray, queue);
+    WFB_TRY(hipMemcpyAsync(&counters[CTR(any ? 3 : 2)], &n, 4, hipMemcpyHostToDevice, stream));
+    WfBuffers W; memset(&W, 0, sizeof(W));
+    W.n_paths = n; W.ray = ray; W.sh = ray; W.hit = hit; W.hit_prim = hit_prim; W.occluded = occluded; W.counters = counters;
+    RenderParams P; memset(&P, 0, sizeof(P)); P.S = S; P.stats = stats;
+    const uint32_t* q = queue;
+    if (knob("FTN_WF_SORT", 1)) { rc = sort_ray_queue(st, P, W, any, queue, n, scratch, scratch + n, scratch + 2 * (size_t)n, 7, stream, &q); if (rc) { cleanup(); return rc; } }
+    const size_t lds = (size_t)stack_entries * 256 * sizeof(uint32_t);
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    const unsigned grid = std::min<unsigned>((unsigned)st->n_cu * per_cu, (n + 255) / 256);
+    launch_trace(any, count, S.n_spheres != 0, grid, st->n_cu, lds, stream, P, W, q, &counters[CTR(any ? 3 : 2)], &counters[CTR(any ? 24 : 16)], n);
+    if (!any) hipLaunchKernelGGL(k_batch_finish, dim3((n + 255) / 256), dim3(256), 0, stream, S, d_rays8, n, hit, hit_prim, t_hit, prim, bary, out24);
+    WFB_TRY(hipStreamSynchronize(stream));
+    WFB_TRY(hipGetLastError());
+#undef WFB_TRY
+    cleanup();
+    return FTN_OK;
+}
+
+int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times) {
+    { int rc0 = wf_state_init(state); if (rc0) return rc0; }
     WavefrontState* st = *state;
     RenderParams P = P0;
     const uint32_t n_slots = (uint32_t)tiles.size() * 256u;
