@@ -883,10 +883,11 @@ static int sort_ray_queue(WavefrontState* st, const RenderParams& P, const WfBuf
     else hipLaunchKernelGGL(k_wf_ray_keys<false>, dim3((cnt + 255) / 256), dim3(256), 0, stream, P.S, W, queue, cnt, k_in, bits);
     const int end_bit = (int)(3 * bits + 3);
     size_t need = 0;
-    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, queue, out, (int)cnt, 0, end_bit, stream));
+    hipcub::DoubleBuffer<uint32_t> keys(k_in, k_out), vals(queue, out);      /* both halves are scratch: the sort ping-pongs instead of copying */
+    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, vals, (int)cnt, 0, end_bit, stream));
     if (need > st->sort_tmp_bytes) { if (st->sort_tmp) (void)hipFree(st->sort_tmp); st->sort_tmp = nullptr; st->sort_tmp_bytes = 0; WF_TRY(hipMalloc(&st->sort_tmp, need)); st->sort_tmp_bytes = need; }
-    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, k_in, k_out, queue, out, (int)cnt, 0, end_bit, stream));
-    *sorted_q = out;
+    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, keys, vals, (int)cnt, 0, end_bit, stream));
+    *sorted_q = vals.Current();
     return FTN_OK;
 }
 
