@@ -82,8 +82,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # one counted step: algorithmic bytes of the dominant kernel (nodes / triangles per ray are data dependent: SURVEY 8(d))
-    cst = step(0, count=True)
+    # one counted step: algorithmic bytes of the dominant kernel (nodes / triangles per ray are data dependent: SURVEY 8(d)).
+    # count_traffic = 2: tally exactly the rays each kernel traces in production (MIS rays toward the environment light only need
+    # hit / miss and go through the any-hit kernel: ftn_stats.mis_rays_any_hit)
+    cst = step(0, count=2)
     dev_film.zero_()
     for i in range(args.warmup):
         step(i)
@@ -120,7 +122,8 @@ def main():
         # ---- roofline of the dominant kernel, k_wf_trace<closest>: algorithmic bytes / its launches' device time
         nodes_c = cst["nodes_visited"] - cst["nodes_visited_any"]
         prims_c = cst["prims_tested"] - cst["prims_tested_any"]
-        bytes_per_step = 32.0 * nodes_c + 48.0 * prims_c + (32.0 + 16.0) * cst["rays_closest"]
+        rays_c = cst["rays_closest"] - cst["mis_rays_any_hit"]          # rays the closest-hit launches traced
+        bytes_per_step = 32.0 * nodes_c + 48.0 * prims_c + (32.0 + 16.0) * rays_c
         launches_per_step = max(cst["trace_launches"], 1)
         bytes_per_launch = bytes_per_step / launches_per_step
         avg_launch_ms = trace_ms / max(trace_launches, 1)
@@ -138,8 +141,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_wf_trace<closest>", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                         "launches_per_step": int(launches_per_step), "nodes_per_ray": round(nodes_c / max(cst["rays_closest"], 1), 2),
-                         "prims_per_ray": round(prims_c / max(cst["rays_closest"], 1), 3)},
+                         "launches_per_step": int(launches_per_step), "rays_per_launch": int(rays_c // launches_per_step),
+                         "nodes_per_ray": round(nodes_c / max(rays_c, 1), 2), "prims_per_ray": round(prims_c / max(rays_c, 1), 3)},
         }
         # HBM-side traffic of the same kernel from PMC counters (collected offline with rocprofv3, see profiles/r01_traffic.json)
         try:

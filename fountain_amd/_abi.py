@@ -132,10 +132,10 @@ class ftn_stats(C.Structure):
     _fields_ = [("rays_closest", c_u64), ("rays_any", c_u64), ("nodes_visited", c_u64), ("prims_tested", c_u64),
                 ("camera_samples", c_u64), ("spill_samples", c_u64), ("kernel_ms", C.c_double),
                 ("trace_ms", C.c_double), ("trace_launches", c_u64), ("nodes_visited_any", c_u64),
-                ("prims_tested_any", c_u64), ("reserved", c_u64 * 1)]
+                ("prims_tested_any", c_u64), ("mis_rays_any_hit", c_u64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # Expected sizes (bytes) -- asserted against the header by the C side's static_asserts and tests/test_abi.py

@@ -936,7 +936,7 @@ class SamplerIntegrator:
                     film.pixels.ctypes.data_as(C.c_void_p), C.byref(st))
         else:
             opt = A.ftn_render_options()
-            opt.pipeline, opt.device, opt.count_traffic = pipeline, device, 1 if count_traffic else 0
+            opt.pipeline, opt.device, opt.count_traffic = pipeline, device, int(count_traffic)
             be.call("render", scene.handle, C.byref(self.camera.desc), C.byref(film.desc), C.byref(sampler.desc),
                     C.byref(self.radiance.desc), C.byref(tr), C.byref(opt),
                     film.pixels.ctypes.data_as(C.c_void_p), C.byref(st))
@@ -953,7 +953,7 @@ class SamplerIntegrator:
         tr.first, tr.stride, tr.count = tiles if tiles is not None else (0, 1, 0)
         st = A.ftn_stats()
         opt = A.ftn_render_options()
-        opt.pipeline, opt.device, opt.count_traffic = pipeline, device, 1 if count_traffic else 0
+        opt.pipeline, opt.device, opt.count_traffic = pipeline, device, int(count_traffic)
         be.call("render_device", scene.handle, C.byref(self.camera.desc), C.byref(film.desc), C.byref(sampler.desc),
                 C.byref(self.radiance.desc), C.byref(tr), C.byref(opt), C.c_void_p(device_pixels_ptr),
                 C.c_void_p(stream_ptr), C.byref(st))

@@ -847,6 +847,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     if (pipeline == FTN_PIPELINE_WAVEFRONT && (!indexed || id->kind != FTN_INTEGRATOR_PATH))
         return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED + FTN_INTEGRATOR_PATH");
     const bool count = opt && opt->count_traffic;
+    const bool count_production = opt && opt->count_traffic == 2;      /* tally the production configuration instead of the reference's walk */
 
     const uint32_t stride = tr && tr->stride ? tr->stride : 1, first = tr ? tr->first : 0, cnt = tr ? tr->count : 0;
     /* the tile list only depends on the film and the tile range: keep it (and its device copy) between calls */
@@ -892,7 +893,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
     WavefrontTimes wt; memset(&wt, 0, sizeof(wt));
-    if (pipeline == FTN_PIPELINE_WAVEFRONT) { rc = wavefront_render(&s->wf, P, sel, count, stream, &wt); if (rc) return fail(rc, wavefront_error()); }
+    if (pipeline == FTN_PIPELINE_WAVEFRONT) { rc = wavefront_render(&s->wf, P, sel, count, stream, &wt, count_production); if (rc) return fail(rc, wavefront_error()); }
     else launch_render_mega(P, count, stream);
     launch_film_resolve(P, (ftn_pixel*)device_pixels, stream);
     HIP_TRY(hipEventRecord(e1, stream));
@@ -900,8 +901,9 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     HIP_TRY(hipGetLastError());
     float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     DevStats ds; HIP_TRY(hipMemcpy(&ds, s->stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+    ds.rays_closest += wt.mis_any_rays; ds.rays_any -= wt.mis_any_rays;       /* they are Scene::intersect calls in the reference's accounting */
     stats_out(ds, st, ms);
-    if (st) { st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; }
+    if (st) { st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; st->mis_rays_any_hit = wt.mis_any_rays; }
     if (ds.error == FTN_ERR_NAN_RADIANCE) return fail(FTN_ERR_NAN_RADIANCE, "NaN radiance value (integrator/mod.rs:285-287)");
     if (ds.error) return fail(ds.error, "unsupported material / integrator combination (e.g. specular glass: material/glass.rs:66)");
     return FTN_OK;

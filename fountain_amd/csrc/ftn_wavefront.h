@@ -9,8 +9,10 @@
 
 namespace ftn {
 struct WavefrontState;
-struct WavefrontTimes { double trace_ms; unsigned long long trace_launches; };
-int wavefront_render(WavefrontState** state, const RenderParams& P, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times);
+struct WavefrontTimes { double trace_ms; unsigned long long trace_launches;
+                        unsigned long long mis_any_rays; /* Scene::intersect calls of estimate_direct answered by the any-hit kernel (infinite lights: only hit / miss matters) */ };
+int wavefront_render(WavefrontState** state, const RenderParams& P, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times,
+                     bool count_production = false);
 /* Scene::intersect (mode 0: t / prim / barycentrics, mode 2: + full interaction in out24) and intersect_test (mode 1) for n rays of
  * 8 floats {o, d, t_max, time} in DEVICE memory; outputs are device pointers (any may be NULL) */
 int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stack_entries, const float* d_rays8, size_t n, int mode, bool count,

@@ -31,7 +31,7 @@
 namespace ftn {
 
 /* pstate bits */
-enum : uint32_t { PS_BOUNCE_MASK = 0xffu, PS_SPECULAR = 1u << 8, PS_ALIVE = 1u << 9, PS_DIRECT = 1u << 10, PS_SHADOW = 1u << 11, PS_MIS = 1u << 12, PS_DELTA = 1u << 13 };
+enum : uint32_t { PS_BOUNCE_MASK = 0xffu, PS_SPECULAR = 1u << 8, PS_ALIVE = 1u << 9, PS_DIRECT = 1u << 10, PS_SHADOW = 1u << 11, PS_MIS = 1u << 12, PS_DELTA = 1u << 13, PS_MIS_ANY = 1u << 14 /* the MIS ray went through the any-hit kernel */ };
 #define WF_MIS_BIT 0x80000000u
 
 struct WfBuffers {
@@ -56,6 +56,7 @@ struct WfBuffers {
     uint32_t seg_cap;           /* capacity of one class segment of q_sorted */
     uint32_t* counters;         /* one 128-byte line each (CTR(i) = 32*i): 0 active A, 1 active B, 2 closest, 3 shadow, 4 head closest, 5 head shadow */
     uint32_t valid_per_sample;  /* camera samples per spp pass (sum of the tiles' pixel counts) */
+    uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
 
 #define CTR(i) ((i) * 32)
@@ -93,10 +94,20 @@ __device__ inline void block_push(const bool (&pred)[NQ], const uint32_t (&value
         if (pred[q]) {
             uint32_t off = s_base[q];
             for (uint32_t w = 0; w < wave; w++) off += s_cnt[q][w];
-            queue[q][off + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull))] = value[q];
+            if (queue[q]) queue[q][off + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull))] = value[q];
         }
     }
     __syncthreads();   /* s_cnt / s_base are reused by the next round */
+}
+
+/* A queue entry is a path id; WF_MIS_BIT marks the path's MIS ray (record n_paths + id) instead of its continuation ray (closest-hit
+ * queue) or its shadow ray (any-hit queue).  *slot: index of the ray's result (hit[] / hit_prim[] for closest hits, occluded[] for
+ * any-hit: shadow results at [0, n_paths), MIS-ray results at [n_paths, 2 n_paths)). */
+template <bool ANY>
+__device__ inline void load_queued_ray(const WfBuffers& W, uint32_t rid, float4* a, float4* b, uint32_t* slot) {
+    const uint32_t pid = rid & ~WF_MIS_BIT;
+    if (ANY && !(rid & WF_MIS_BIT)) { *a = W.sh[2 * (size_t)pid]; *b = W.sh[2 * (size_t)pid + 1]; *slot = pid; }
+    else { const uint32_t r = (rid & WF_MIS_BIT) ? pid + W.n_paths : pid; *a = W.ray[2 * (size_t)r]; *b = W.ray[2 * (size_t)r + 1]; *slot = r; }
 }
 
 /* ------------------------------------------------------------------ generate (no atomics: queue slots are known in closed form) */
@@ -233,9 +244,8 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (mode == TM_IDLE && rank < avail) {
-                rid = queue[chunk_next + rank];
-                const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
-                const float4 a = ANY ? W.sh[2 * (size_t)(r)] : W.ray[2 * (size_t)(r)], b = ANY ? W.sh[2 * (size_t)(r) + 1] : W.ray[2 * (size_t)(r) + 1];
+                float4 a, b;
+                load_queued_ray<ANY>(W, queue[chunk_next + rank], &a, &b, &rid);      /* rid: the result slot of this ray from here on */
                 o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
                 if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 sptr = st_base; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
                 mode = TM_NODE;
                 if (S.n_nodes == 0) {   /* empty scene: immediate miss */
-                    if (ANY) W.occluded[rid] = 0; else { W.hit[r] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[r] = -1; }
+                    if (ANY) W.occluded[rid] = 0; else { W.hit[rid] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[rid] = -1; }
                     mode = TM_IDLE;
                 }
             }
@@ -298,10 +308,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
         }
         if (finish) {
             if (ANY) W.occluded[rid] = found ? 1 : 0;
-            else {
-                const uint32_t r = (rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid;
-                W.hit[r] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[r] = hprim;
-            }
+            else { W.hit[rid] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[rid] = hprim; }
             mode = TM_IDLE;
         }
     }
@@ -385,9 +392,8 @@ __global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, con
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (mode == TM_IDLE && rank < avail) {
-                rid = queue[chunk_next + rank];
-                const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid);
-                const float4 a = ANY ? W.sh[2 * (size_t)(r)] : W.ray[2 * (size_t)(r)], b = ANY ? W.sh[2 * (size_t)(r) + 1] : W.ray[2 * (size_t)(r) + 1];
+                float4 a, b;
+                load_queued_ray<ANY>(W, queue[chunk_next + rank], &a, &b, &rid);      /* rid: the result slot of this ray from here on */
                 o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
                 if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -398,7 +404,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, con
                 /* the root's own box test (bvh.rs:174-176) */
                 const bool root_hit = S.n_nodes != 0 && slab_test(rlo, rhi, o, inv, t_max);
                 if (!root_hit) {
-                    if (ANY) W.occluded[rid] = 0; else { W.hit[r] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[r] = -1; }
+                    if (ANY) W.occluded[rid] = 0; else { W.hit[rid] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[rid] = -1; }
                     mode = TM_IDLE;
                 } else if (S.root_is_leaf) { lp = 0; mode = TM_LEAF; }
                 else mode = TM_NODE;
@@ -467,10 +473,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, con
         }
         if (finish) {
             if (ANY) W.occluded[rid] = found ? 1 : 0;
-            else {
-                const uint32_t r = (rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + np : rid;
-                W.hit[r] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[r] = hprim;
-            }
+            else { W.hit[rid] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[rid] = hprim; }
             mode = TM_IDLE;
         }
     }
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
             have = qi - cb < cc;
             sorted_idx = c * W.seg_cap + (qi - cb);
         }
-        bool push_active = false, push_closest = false, push_mis = false, push_shadow = false;
+        bool push_active = false, push_closest = false, push_mis = false, push_shadow = false, push_mis_any = false;
         uint32_t p = 0;
         if (have) {
             p = W.q_sorted[sorted_idx];
@@ -589,7 +592,14 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 const float4 q0 = W.pend0[p], q1 = W.pend1[p], q2 = W.pend2[p];
                 Rgb radiance(0.0f);
                 if ((ps & PS_SHADOW) && !W.occluded[p]) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
-                if (ps & PS_MIS) {
+                if (ps & PS_MIS_ANY) {                           /* infinite light: the BSDF-sampled ray either escapes to it or contributes nothing (mod.rs:367-384) */
+                    const int light_index = (int)__float_as_uint(lq.w);
+                    const DLight& Lt = S.lights[light_index];
+                    const float4 md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
+                    Rgb inc(0.0f);
+                    if (!W.occluded[p + W.n_paths]) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
+                    if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
+                } else if (ps & PS_MIS) {
                     const int light_index = (int)__float_as_uint(lq.w);
                     const DLight& Lt = S.lights[light_index];
                     const DHit mh = load_hit(W, p + W.n_paths);
@@ -607,7 +617,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 }
                 Rgb direct = Rgb(q2.x, q2.y, q2.z) * ((float)S.n_lights * radiance);
                 L = L + direct;
-                ps &= ~(PS_DIRECT | PS_SHADOW | PS_MIS);
+                ps &= ~(PS_DIRECT | PS_SHADOW | PS_MIS | PS_MIS_ANY);
             }
             if (!(ps & PS_ALIVE)) {
                 W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);     /* path finished: final radiance */
@@ -690,7 +700,8 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                                 DRay mr = spawn_ray(si.hit, sc.wi);
                                                 W.ray[2 * (size_t)(p + W.n_paths)] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
                                                 W.ray[2 * (size_t)(p + W.n_paths) + 1] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
-                                                mis_f = f; mis_pdf = sc.pdf; ps |= PS_MIS; push_mis = true;
+                                                mis_f = f; mis_pdf = sc.pdf;
+                                                if (W.mis_any && Lt.kind == LK_INFINITE) { ps |= PS_MIS_ANY; push_mis_any = true; } else { ps |= PS_MIS; push_mis = true; }
                                             }
                                         }
                                     }
@@ -728,11 +739,11 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
             }
         }
         {
-            const bool pred[4] = {push_active, push_closest, push_mis, push_shadow};
-            const uint32_t val[4] = {p, p, p | WF_MIS_BIT, p};
-            uint32_t* const qs[4] = {out_q, W.q_closest, W.q_closest, W.q_shadow};
-            uint32_t* const cs[4] = {out_count, &W.counters[CTR(2)], &W.counters[CTR(2)], &W.counters[CTR(3)]};
-            block_push<4>(pred, val, qs, cs);
+            const bool pred[6] = {push_active, push_closest, push_mis, push_shadow, push_mis_any, push_mis_any};
+            const uint32_t val[6] = {p, p, p | WF_MIS_BIT, p, p | WF_MIS_BIT, 0u};
+            uint32_t* const qs[6] = {out_q, W.q_closest, W.q_closest, W.q_shadow, W.q_shadow, nullptr};        /* the last "queue" only counts (CTR(10)): MIS rays traced as any-hit */
+            uint32_t* const cs[6] = {out_count, &W.counters[CTR(2)], &W.counters[CTR(2)], &W.counters[CTR(3)], &W.counters[CTR(3)], &W.counters[CTR(10)]};
+            block_push<6>(pred, val, qs, cs);
         }
     }
     if (err) atomicCAS(&P.stats->error, 0, err);
@@ -823,9 +834,8 @@ template <bool ANY>
 __global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, uint32_t count, uint32_t* __restrict__ keys, uint32_t bits) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= count) return;
-    const uint32_t rid = queue[i];
-    const uint32_t r = ANY ? rid : ((rid & WF_MIS_BIT) ? (rid & ~WF_MIS_BIT) + W.n_paths : rid);
-    const float4 a = ANY ? W.sh[2 * (size_t)(r)] : W.ray[2 * (size_t)(r)], b = ANY ? W.sh[2 * (size_t)(r) + 1] : W.ray[2 * (size_t)(r) + 1];
+    float4 a, b; uint32_t slot;
+    load_queued_ray<ANY>(W, queue[i], &a, &b, &slot);
     const float ex = S.root_hi[0] - S.root_lo[0], ey = S.root_hi[1] - S.root_lo[1], ez = S.root_hi[2] - S.root_lo[2];
     const float sc = (float)(1u << bits);
     const float fx = fminf(fmaxf((a.x - S.root_lo[0]) / ex, 0.0f), 0.999f) * sc, fy = fminf(fmaxf((a.y - S.root_lo[1]) / ey, 0.0f), 0.999f) * sc, fz = fminf(fmaxf((a.z - S.root_lo[2]) / ez, 0.0f), 0.999f) * sc;
@@ -864,9 +874,9 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     wf_free(st);
     WfBuffers& W = st->W; int rc;
     if ((rc = wf_alloc(st, &W.ray, 4 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
-        (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
+        (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
-        (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
+        (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
         (rc = wf_alloc(st, &W.counters, 32 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
@@ -996,7 +1006,8 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
     return FTN_OK;
 }
 
-int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times) {
+int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times,
+                     bool count_production) {
     { int rc0 = wf_state_init(state); if (rc0) return rc0; }
     WavefrontState* st = *state;
     RenderParams P = P0;
@@ -1012,11 +1023,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
+    W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1) && !knob("FTN_TRACE_FAT", 0)) ? 1u : 0u;
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
     const unsigned shade_grid_max = (unsigned)st->n_cu * 8u;
-    double trace_ms = 0.0; unsigned long long trace_launches = 0;
+    double trace_ms = 0.0; unsigned long long trace_launches = 0, mis_any_rays = 0;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     int ev_used = 0;
     struct Span { int a, b; };
@@ -1045,8 +1057,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
             if (it > 0) {
-                const unsigned sg = std::min<unsigned>(trace_grid_max, (W.n_paths + 255) / 256);
-                launch_trace(true, count, spheres, sg, st->n_cu, lds, stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], W.n_paths);
+                const unsigned sg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
+                launch_trace(true, count, spheres, sg, st->n_cu, lds, stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);
             }
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
@@ -1073,7 +1085,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 WF_TRY(hipStreamSynchronize(stream));
                 polled = true;
                 const size_t n = st->cap_paths;                        /* scratch: q_sorted is free until the next classify */
-                uint32_t* const k_in = W.q_sorted + 3 * n, *const k_out = W.q_sorted + 5 * n;
+                uint32_t* const k_in = W.q_sorted + 4 * n, *const k_out = W.q_sorted + 6 * n;     /* [0,2n) sorted closest, [2n,4n) sorted any-hit, keys in / out */
                 q_cl = W.q_closest; q_sh = W.q_shadow;
                 if ((rc = sort_ray_queue(st, P, W, false, W.q_closest, st->host_counters[CTR(2)], W.q_sorted, k_in, k_out, sort_bits, stream, &q_cl))) return rc;
                 if ((rc = sort_ray_queue(st, P, W, true, W.q_shadow, st->host_counters[CTR(3)], W.q_sorted + 2 * n, k_in, k_out, sort_bits, stream, &q_sh))) return rc;
@@ -1087,11 +1099,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
             }
         }
+        if (W.mis_any) mis_any_rays += st->host_counters[CTR(10)];   /* the last poll of the pass saw the pass's total */
         hipLaunchKernelGGL(k_wf_accumulate, dim3((n_slots + 255) / 256), dim3(256), 0, stream, P, W);
     }
     rc = flush_events(); if (rc) return rc;
     WF_TRY(hipGetLastError());
-    if (times) { times->trace_ms = trace_ms; times->trace_launches = trace_launches; }
+    if (times) { times->trace_ms = trace_ms; times->trace_launches = trace_launches; times->mis_any_rays = mis_any_rays; }
     return FTN_OK;
 }
 

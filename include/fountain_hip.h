@@ -262,7 +262,9 @@ enum {
 typedef struct ftn_render_options {
     uint32_t pipeline;        /* FTN_PIPELINE_*                                                 */
     int32_t device;           /* HIP device ordinal; -1 = current                               */
-    uint32_t count_traffic;   /* 1: also tally nodes visited / prims tested (slower)            */
+    uint32_t count_traffic;   /* 1: also tally nodes visited / prims tested with the reference's traversal for every ray (slower; equals the
+                                    oracle's tally); 2: tally what the production configuration really walks (MIS rays toward an
+                                    infinite light go through the any-hit kernel, see ftn_stats.mis_rays_any_hit)        */
     uint32_t _pad;
 } ftn_render_options;
 
@@ -278,7 +280,8 @@ typedef struct ftn_stats {
     uint64_t trace_launches;    /* closest-hit traversal launches timed by trace_ms (wavefront)            */
     uint64_t nodes_visited_any; /* the share of nodes_visited / prims_tested spent in intersect_test rays   */
     uint64_t prims_tested_any;
-    uint64_t reserved[1];
+    uint64_t mis_rays_any_hit;  /* Scene::intersect calls of estimate_direct (integrator/mod.rs:367) answered by the any-hit kernel: toward an
+                                   infinite light only hit / miss matters.  Included in rays_closest (the reference's accounting).      */
 } ftn_stats;
 
 /* ------------------------------------------------------------------ host-side constructors
