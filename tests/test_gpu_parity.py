@@ -309,6 +309,35 @@ def test_ray_queue_sort_changes_nothing(gpu, monkeypatch):
         assert stats[0][k] == stats[1][k], k
 
 
+def test_mis_rays_through_the_any_hit_kernel_change_nothing(gpu, orc_det, monkeypatch):
+    """estimate_direct's BSDF-sampled ray toward an INFINITE light only needs hit / miss (integrator/mod.rs:367-384: a hit primitive can
+    only contribute if it is THIS area light), so outside the reference-order counting build it goes through the any-hit kernel.
+    Same film bit for bit, same ray counts in the reference's accounting, and identical to the oracle."""
+    make = lambda be: scenes.instanced_cubes(be, n_copies=27, res=(160, 160), env_n=32)
+    b, cam, res = make(gpu)
+    sc = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    films, stats = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FTN_MIS_ANY", flag)
+        f = Film(gpu, res)
+        stats[flag] = si.render_parallel(sc, f, RandomSampler(2, 0, indexed=True), pipeline=WAVE)
+        films[flag] = f.pixels
+    monkeypatch.delenv("FTN_MIS_ANY")
+    assert np.array_equal(bits(films["1"]), bits(films["0"]))
+    assert stats["1"]["mis_rays_any_hit"] > 0 and stats["0"]["mis_rays_any_hit"] == 0
+    assert stats["1"]["rays_closest"] == stats["0"]["rays_closest"] and stats["1"]["rays_any"] == stats["0"]["rays_any"]
+    counted = si.render_parallel(sc, Film(gpu, res), RandomSampler(2, 0, indexed=True), pipeline=WAVE, count_traffic=True)
+    assert counted["mis_rays_any_hit"] == 0 and counted["rays_closest"] == stats["1"]["rays_closest"]          # reference-order tally
+    prod = si.render_parallel(sc, Film(gpu, res), RandomSampler(2, 0, indexed=True), pipeline=WAVE, count_traffic=2)
+    assert prod["mis_rays_any_hit"] == stats["1"]["mis_rays_any_hit"] and prod["nodes_visited"] < counted["nodes_visited"]   # early exits
+    bo, camo, _ = make(orc_det)
+    fo = Film(orc_det, res)
+    sto = SamplerIntegrator(camo, PathIntegrator.new(5, 1.0)).render_parallel(bo.create_scene(), fo, RandomSampler(2, 0, indexed=True))
+    assert_film_equal(films["1"], fo.pixels, stats["1"]["spill_samples"], "mis-any vs oracle")
+    assert sto["rays_closest"] == stats["1"]["rays_closest"] and sto["rays_any"] == stats["1"]["rays_any"]
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_specular_glass_reports_unsupported(gpu):
     b = SceneBuilder(gpu)
