@@ -64,9 +64,9 @@ struct DScene {
     const DSphere* spheres; const ftn_material* materials; const DLight* lights;
     uint32_t n_nodes, n_prims, n_lights, n_inf_lights, n_spheres, _pad;
     const uint32_t* inf_lights;             /* indices of infinite lights (environment_emitted_radiance sums all lights) */
-    /* second view of the same BVH for the fast traversal kernels: one 64-byte record per INTERIOR node holding both children's boxes
-     *   {c0.bmin, bits(meta0)} {c0.bmax, bits(ptr0)} {c1.bmin, bits(meta1)} {c1.bmax, bits(ptr1)}
-     * meta: bit 31 = child is a leaf; meta0 bits 16..17 = split axis of this node. ptr: record index of an interior child, first primitive of a leaf */
+    /* second view of the same BVH for the any-hit kernel (k_wf_trace_any2): one 64-byte record per INTERIOR node = its two children's
+     * node records side by side, {min.x,max.x,min.y,max.y} {min.z,max.z,bits(link),bits(meta)} each; link = byte offset of an interior
+     * child's own record / first primitive of a leaf child; meta = n_prims | leaf<<24, record 0 also carries onehot(this node's axis)<<16 */
     const float4* fat;
     float root_lo[3], root_hi[3];
     uint32_t root_is_leaf, n_fat;

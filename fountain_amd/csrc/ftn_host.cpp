@@ -560,7 +560,8 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         const uint32_t link = n.is_leaf ? n.idx : n.idx * 32u;
         nodes[2 * i + 1] = make_float4(n.bmin[2], n.bmax[2], ftn_det::u2f(link), ftn_det::u2f((uint32_t)n.n_prims | ((1u << n.axis) << 16) | ((uint32_t)n.is_leaf << 24)));
     }
-    /* fat records (see DScene::fat): one per interior node, numbered in DFS order */
+    /* two-box records (see DScene::fat): one per interior node, numbered in DFS order */
+    if (hs.nodes.size() > (1u << 25)) return fail(FTN_ERR_UNSUPPORTED, "more than 2^25 BVH nodes");           /* record offsets are 31-bit byte offsets */
     std::vector<uint32_t> fat_id(hs.nodes.size(), 0xffffffffu);
     uint32_t n_fat = 0;
     for (size_t i = 0; i < hs.nodes.size(); i++) if (!hs.nodes[i].is_leaf) fat_id[i] = n_fat++;
@@ -570,13 +571,12 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         const ftn_bvh_node& n = hs.nodes[i];
         if (n.is_leaf) { if (n.n_prims) leaf_end[n.idx + n.n_prims - 1] = 1; continue; }
         const size_t ch[2] = {i + 1, (size_t)n.idx};
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 2; k++) {                            /* the two children's node records side by side (same layout as `nodes`) */
             const ftn_bvh_node& c = hs.nodes[ch[k]];
-            uint32_t meta = c.is_leaf ? 0x80000000u : 0u;
-            if (k == 0) meta |= (uint32_t)n.axis << 16;
-            const uint32_t ptr = c.is_leaf ? c.idx : fat_id[ch[k]];
-            fat[4 * (size_t)fat_id[i] + 2 * k] = make_float4(c.bmin[0], c.bmin[1], c.bmin[2], ftn_det::u2f(meta));
-            fat[4 * (size_t)fat_id[i] + 2 * k + 1] = make_float4(c.bmax[0], c.bmax[1], c.bmax[2], ftn_det::u2f(ptr));
+            const uint32_t link = c.is_leaf ? c.idx : fat_id[ch[k]] * 64u;            /* byte offset of the child's own two-box record, or first primitive */
+            const uint32_t meta = (uint32_t)c.n_prims | (k == 0 ? ((1u << n.axis) << 16) : 0u) | ((uint32_t)c.is_leaf << 24);   /* record 0 carries THIS node's split axis */
+            fat[4 * (size_t)fat_id[i] + 2 * k] = make_float4(c.bmin[0], c.bmax[0], c.bmin[1], c.bmax[1]);
+            fat[4 * (size_t)fat_id[i] + 2 * k + 1] = make_float4(c.bmin[2], c.bmax[2], ftn_det::u2f(link), ftn_det::u2f(meta));
         }
     }
     std::vector<int> prim_light(np, -1);

@@ -325,126 +325,88 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
     if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
 }
 
-/* ------------------------------------------------------------------ trace, fast variant: 64-byte records with both children's boxes
+/* ------------------------------------------------------------------ any-hit traversal over two-box records
  *
- * k_wf_trace fetches every visited node, including the ones whose box test fails, and every fetch of a 32-byte node pulls a
- * 128-byte line from HBM.  Here a lane sits on an INTERIOR node that has already passed its box test and reads one 64-byte
- * record with both children's boxes (DScene::fat): children that fail are never fetched.
- *
- * The primitives tested, their order and every t_max update are exactly those of bvh.rs:160-266:
- *   - near child (by dir_is_neg[axis]): its slab test runs now, with the current t_max - the reference runs the same test at
- *     this point (it visits the near child next and nothing happens in between);
- *   - far child: the reference tests its box when it is popped, with the t_max of that moment.  The slab test is
- *         fail  <=>  t0 > min(t_max, F),   t0 = max(0, near-plane distances),  F = min(far-plane distances * (1+2 gamma(3)))
- *     (the per-axis early exits of bounds.rs:214-233 are equivalent to this single comparison because the running t0 only grows
- *     and the running t1 only shrinks; fmaxf/fminf ignore NaNs exactly like f32::max/min).  t0 and F do not depend on t_max.
- *     So: if t0 > F or t0 > t_max now, the later test fails too (t_max only shrinks) and the child is dropped; otherwise
- *     (child, t0) is pushed and the popped entry is culled iff t0 > t_max then - the same boolean the reference computes.
- * Stack entry: {child, t0} in LDS ([level][lane], two planes); the sign bit of t0 (t0 >= 0) marks a leaf child.
- * Leaf primitives are walked until the GF_LEAF_END flag.  Used when traffic counters are off; k_wf_trace remains the
- * reference-order kernel that tallies nodes/primitives for the roofline's algorithmic bytes. */
-struct SlabOut { bool hit; float t0; };
-__device__ inline SlabOut slab_test2(float4 lo, float4 hi, V3 o, V3 inv, float t_max) {
-    const float k = 1.0f + 2.0f * gamma_n(3);
-    float tnx = (lo.x - o.x) * inv.x, tfx = (hi.x - o.x) * inv.x;
-    float tny = (lo.y - o.y) * inv.y, tfy = (hi.y - o.y) * inv.y;
-    float tnz = (lo.z - o.z) * inv.z, tfz = (hi.z - o.z) * inv.z;
-    if (tnx > tfx) { float s = tnx; tnx = tfx; tfx = s; }
-    if (tny > tfy) { float s = tny; tny = tfy; tfy = s; }
-    if (tnz > tfz) { float s = tnz; tnz = tfz; tfz = s; }
-    tfx *= k; tfy *= k; tfz *= k;
-    const float t0x = fmax_(0.0f, tnx), t1x = fmin_(t_max, tfx);
-    const float t0y = fmax_(t0x, tny), t1y = fmin_(t1x, tfy);
-    const float t0z = fmax_(t0y, tnz), t1z = fmin_(t1y, tfz);
-    SlabOut r; r.hit = !(t0z > t1z); r.t0 = t0z;      /* see slab_test: the last comparison subsumes the earlier ones */
-    return r;
-}
-
-template <bool ANY, bool SPHERES>
-__global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
-                                                      DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t node_burst, uint32_t stack_entries) {
+ * Scene::intersect_test returns a boolean, and t_max never shrinks while it walks: whether a box or a triangle is reached does not
+ * depend on the order of the walk.  So the any-hit kernel is free to test BOTH children of an interior node in one step from one
+ * 64-byte record (DScene::fat: the two children's node records side by side) and to descend only into children whose box the ray
+ * enters -- a node that fails its test is never fetched, and a step advances two levels' worth of box tests per memory round trip.
+ * (For closest hits the far child must be re-tested against the shrunken t_max when it is popped; carrying its entry distance on
+ * the stack doubles the LDS per lane and was measured slower, see DESIGN.md.)  The stack entry is one word: byte offset of an
+ * interior child's record, or first primitive | bit 31 for a leaf child; leaf primitives are walked until GF_LEAF_END.
+ * The counting build keeps k_wf_trace<ANY> (the reference's walk) so that node tallies equal the oracle's. */
+template <bool SPHERES>
+__global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head,
+                                                       DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk) {
     extern __shared__ uint32_t lds_stack[];
-    uint32_t* const st_idx = lds_stack + threadIdx.x;                              /* [level][lane] */
-    float* const st_t0 = reinterpret_cast<float*>(lds_stack + stack_entries * 256u) + threadIdx.x;
+    uint32_t* const st_base = lds_stack + threadIdx.x;
+    uint32_t* sptr = st_base;
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
-    const uint32_t np = W.n_paths;
     uint32_t mode = TM_IDLE;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
+    uint32_t slice = blockIdx.x & 7u, slices_done = 0;                     /* one queue slice per XCD, see k_wf_trace */
     { uint32_t c = count / (gridDim.x * 4u * 16u); c &= ~63u; chunk = c < 64u ? 64u : (c > chunk ? chunk : c); }
-    uint32_t rid = 0, cur = 0, neg = 0, lp = 0; int sp = 0;
-    V3 o, inv; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kz = 0;
-    int hprim = -1; float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f; bool found = false;
+    uint32_t rid = 0, cur = 0, neg16 = 0, lp = 0;
+    V3 o, inv, dperm; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kz = 0;
+    bool found = false;
     V3 dorig;
     const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f), rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
     for (;;) {
         const unsigned long long idle = __ballot(mode == TM_IDLE);
         if (!exhausted && (uint32_t)__popcll(idle) >= refill) {
             const uint32_t need = (uint32_t)__popcll(idle);
-            if (chunk_next == chunk_end) {
+            while (chunk_next == chunk_end && !exhausted) {
+                const uint32_t s_lo = (uint32_t)(((unsigned long long)count * slice) >> 3) & ~63u, s_hi = slice == 7u ? count : ((uint32_t)(((unsigned long long)count * (slice + 1u)) >> 3) & ~63u);
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, chunk);
-                base = __shfl(base, 0, 64);
-                chunk_next = base; chunk_end = base + chunk;
-                if (chunk_next >= count) { exhausted = true; chunk_end = chunk_next; }
-                else if (chunk_end > count) chunk_end = count;
+                if (lane == 0) base = atomicAdd(head + CTR(slice), chunk);
+                base = __shfl(base, 0, 64) + s_lo;
+                if (base >= s_hi) { slice = (slice + 1u) & 7u; if (++slices_done == 8u) exhausted = true; }
+                else { chunk_next = base; chunk_end = base + chunk < s_hi ? base + chunk : s_hi; }
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (mode == TM_IDLE && rank < avail) {
                 float4 a, b;
-                load_queued_ray<ANY>(W, queue[chunk_next + rank], &a, &b, &rid);      /* rid: the result slot of this ray from here on */
+                load_queued_ray<true>(W, queue[chunk_next + rank], &a, &b, &rid);
                 o = V3(a.x, a.y, a.z); const V3 d(b.x, b.y, b.z); t_max = b.w;
                 if (SPHERES) dorig = d;
                 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+                neg16 = (d.x < 0.0f ? 0x10000u : 0u) | (d.y < 0.0f ? 0x20000u : 0u) | (d.z < 0.0f ? 0x40000u : 0u);
                 kz = max_dimension(vabs(d));
-                { const int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1; const V3 dp(d.get(kx), d.get(ky), d.get(kz)); sx = -dp.x / dp.z; sy = -dp.y / dp.z; sz = 1.0f / dp.z; }
-                sp = 0; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
-                /* the root's own box test (bvh.rs:174-176) */
-                const bool root_hit = S.n_nodes != 0 && slab_test(rlo, rhi, o, inv, t_max);
-                if (!root_hit) {
-                    if (ANY) W.occluded[rid] = 0; else { W.hit[rid] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[rid] = -1; }
-                    mode = TM_IDLE;
-                } else if (S.root_is_leaf) { lp = 0; mode = TM_LEAF; }
+                { const int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1; dperm = V3(d.get(kx), d.get(ky), d.get(kz)); }
+                sx = -dperm.x / dperm.z; sy = -dperm.y / dperm.z; sz = 1.0f / dperm.z;
+                sptr = st_base; cur = 0; found = false;
+                /* the root's own box test (bvh.rs:228-230) */
+                if (S.n_nodes == 0 || !slab_test(rlo, rhi, o, inv, t_max)) { W.occluded[rid] = 0; mode = TM_IDLE; }
+                else if (S.root_is_leaf) { lp = 0; mode = TM_LEAF; }
                 else mode = TM_NODE;
             }
             chunk_next += (need < avail ? need : avail);
         }
         const unsigned long long m_node = __ballot(mode == TM_NODE), m_leaf = __ballot(mode == TM_LEAF);
         if ((m_node | m_leaf) == 0) { if (exhausted) break; else continue; }
-        bool finish = false, need_pop = false;
+        bool finish = false;
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
-            for (uint32_t burst = 0; burst < node_burst; burst++) {
+#pragma unroll
+            for (uint32_t burst = 0; burst < 4u; burst++) {
                 if (mode == TM_NODE && !finish) {
-                    float4 f0 = S.fat[4 * (size_t)cur], f1 = S.fat[4 * (size_t)cur + 1], f2 = S.fat[4 * (size_t)cur + 2], f3 = S.fat[4 * (size_t)cur + 3];
-                    pin4(f0); pin4(f1); pin4(f2); pin4(f3);
-                    const uint32_t axis = (__float_as_uint(f0.w) >> 16) & 3u;
-                    const bool swap = ((neg >> axis) & 1u) != 0;                  /* dir_is_neg[axis]: second child first */
-                    const float4 nlo = swap ? f2 : f0, nhi = swap ? f3 : f1, flo = swap ? f0 : f2, fhi = swap ? f1 : f3;
-                    const SlabOut hn = slab_test2(nlo, nhi, o, inv, t_max);
-                    const SlabOut hf = slab_test2(flo, fhi, o, inv, t_max);
-                    if (hf.hit) {                                                 /* keep the far child for later, with its entry distance */
-                        const bool leaf = (__float_as_uint(flo.w) >> 31) != 0;
-                        st_idx[sp * 256] = __float_as_uint(fhi.w);
-                        st_t0[sp * 256] = leaf ? -hf.t0 : hf.t0;
-                        sp++;
-                    }
-                    if (hn.hit) {
-                        if (__float_as_uint(nlo.w) >> 31) { lp = __float_as_uint(nhi.w); mode = TM_LEAF; }
-                        else cur = __float_as_uint(nhi.w);
-                    } else need_pop = true;
-                    /* pop: drop entries whose box the ray no longer reaches (t0 > t_max) */
-                    while (need_pop) {
-                        if (sp == 0) { finish = true; need_pop = false; break; }
-                        --sp;
-                        const float e = st_t0[sp * 256];
-                        const uint32_t id = st_idx[sp * 256];
-                        if (!(fabsf(e) > t_max)) {
-                            need_pop = false;
-                            if (ftn_det::f2u(e) >> 31) { lp = id; mode = TM_LEAF; } else cur = id;
-                        }
-                    }
+                    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.fat) + cur);
+                    float4 a0 = rec[0], b0 = rec[1], a1 = rec[2], b1 = rec[3];
+                    pin4(a0); pin4(b0); pin4(a1); pin4(b1);
+                    const bool h0 = slab_test_node(a0, b0, o, inv, t_max), h1 = slab_test_node(a1, b1, o, inv, t_max);
+                    const uint32_t m0 = __float_as_uint(b0.w), m1 = __float_as_uint(b1.w);
+                    /* stack / next entries: byte offset of the child's record, or first primitive | bit 31 for a leaf child */
+                    const uint32_t e0 = __float_as_uint(b0.z) | ((m0 >> 24) ? 0x80000000u : 0u), e1 = __float_as_uint(b1.z) | ((m1 >> 24) ? 0x80000000u : 0u);
+                    const bool second_first = (m0 & neg16) != 0;            /* dir_is_neg[split axis]: nearer child first, occluders near the origin end the walk soonest */
+                    const uint32_t en = second_first ? e1 : e0, ef = second_first ? e0 : e1;
+                    const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
+                    uint32_t next = 0; bool have = true;
+                    if (hn) { next = en; if (hf) { *sptr = ef; sptr += 256; } }
+                    else if (hf) next = ef;
+                    else if (sptr == st_base) { finish = true; have = false; }
+                    else { sptr -= 256; next = *sptr; }
+                    if (have) { if (next >> 31) { lp = next & 0x7fffffffu; mode = TM_LEAF; } else cur = next; }
                 }
             }
         } else {
@@ -454,30 +416,16 @@ __global__ void __launch_bounds__(256) k_wf_trace_fat(DScene S, WfBuffers W, con
                 pin4(g0); pin4(g1); pin4(g2);
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 const bool hh = prim_hit<SPHERES>(S, prim, g0, g1, g2, o, dorig, t_max, kz, sx, sy, sz, &t, &b0, &b1, &b2);
-                if (hh) { found = true; t_max = t; hprim = (int)prim; hb0 = b0; hb1 = b1; hb2 = b2; }
-                if (ANY && hh) finish = true;
+                if (hh) { found = true; finish = true; }
                 else if (__float_as_uint(g0.w) & GF_LEAF_END) {
-                    bool popping = true;
-                    while (popping) {
-                        if (sp == 0) { finish = true; break; }
-                        --sp;
-                        const float e = st_t0[sp * 256];
-                        const uint32_t id = st_idx[sp * 256];
-                        if (!(fabsf(e) > t_max)) {
-                            popping = false;
-                            if (ftn_det::f2u(e) >> 31) { lp = id; mode = TM_LEAF; } else { cur = id; mode = TM_NODE; }
-                        }
-                    }
+                    if (sptr == st_base) finish = true;
+                    else { sptr -= 256; const uint32_t next = *sptr; if (next >> 31) lp = next & 0x7fffffffu; else { cur = next; mode = TM_NODE; } }
                 } else lp++;
             }
         }
-        if (finish) {
-            if (ANY) W.occluded[rid] = found ? 1 : 0;
-            else { W.hit[rid] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[rid] = hprim; }
-            mode = TM_IDLE;
-        }
+        if (finish) { W.occluded[rid] = found ? 1 : 0; mode = TM_IDLE; }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
 }
 
 /* ------------------------------------------------------------------ material-sorted shading: group the active queue by shading class
@@ -910,15 +858,9 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
-    if (!count && knob("FTN_TRACE_FAT", 0)) {      /* measured slower on MI355X: kept as an exact alternative */
-        const size_t lds2 = 2 * lds;                                                   /* {child, t0} per level */
-        const uint32_t depth = (uint32_t)(lds / (256 * sizeof(uint32_t)));
-        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds2, 1)));
-        const unsigned g2 = std::min<unsigned>(grid, (unsigned)n_cu * per_cu);
-#define FTN_TF(A, Sp) if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_wf_trace_fat<A, Sp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
-        hipLaunchKernelGGL((k_wf_trace_fat<A, Sp>), dim3(g2), dim3(256), lds2, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst, depth)
-        if (any) { if (spheres) { FTN_TF(true, true); } else { FTN_TF(true, false); } } else { if (spheres) { FTN_TF(false, true); } else { FTN_TF(false, false); } }
-#undef FTN_TF
+    if (any && !count && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
+        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk);
+        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk);
         return;
     }
     lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
@@ -1023,7 +965,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
-    W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1) && !knob("FTN_TRACE_FAT", 0)) ? 1u : 0u;
+    W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
