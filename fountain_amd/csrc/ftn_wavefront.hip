@@ -1034,7 +1034,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 uint32_t* const k_in = W.q_sorted + 4 * n, *const k_out = W.q_sorted + 6 * n;     /* [0,2n) sorted closest, [2n,4n) sorted any-hit, keys in / out */
                 q_cl = W.q_closest; q_sh = W.q_shadow;
                 if ((rc = sort_ray_queue(st, P, W, false, W.q_closest, st->host_counters[CTR(2)], W.q_sorted, k_in, k_out, sort_bits, stream, &q_cl))) return rc;
-                if ((rc = sort_ray_queue(st, P, W, true, W.q_shadow, st->host_counters[CTR(3)], W.q_sorted + 2 * n, k_in, k_out, sort_bits, stream, &q_sh))) return rc;
+                /* the any-hit queue stays in shading order: with the two-box kernel its sort (24 M entries per step) costs more than it returns */
+                if (knob("FTN_WF_SORT_ANY", 0) && (rc = sort_ray_queue(st, P, W, true, W.q_shadow, st->host_counters[CTR(3)], W.q_sorted + 2 * n, k_in, k_out, sort_bits, stream, &q_sh))) return rc;
             }
             if (it >= P.max_depth || polled) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
                 if (!polled) {
