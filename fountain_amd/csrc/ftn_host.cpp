@@ -561,7 +561,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         nodes[2 * i + 1] = make_float4(n.bmin[2], n.bmax[2], ftn_det::u2f(link), ftn_det::u2f((uint32_t)n.n_prims | ((1u << n.axis) << 16) | ((uint32_t)n.is_leaf << 24)));
     }
     /* two-box records (see DScene::fat): one per interior node, numbered in DFS order */
-    if (hs.nodes.size() > (1u << 25)) return fail(FTN_ERR_UNSUPPORTED, "more than 2^25 BVH nodes");           /* record offsets are 31-bit byte offsets */
+    if (hs.nodes.size() >= (1u << 27)) return fail(FTN_ERR_UNSUPPORTED, "more than 2^27 BVH nodes (node links are 32-bit byte offsets)");
     std::vector<uint32_t> fat_id(hs.nodes.size(), 0xffffffffu);
     uint32_t n_fat = 0;
     for (size_t i = 0; i < hs.nodes.size(); i++) if (!hs.nodes[i].is_leaf) fat_id[i] = n_fat++;
@@ -607,7 +607,8 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     int rc;
     if ((rc = sc->nodes.upload(nodes.data(), nodes.size()))) return rc;
     if ((rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
-    if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc;
+    /* two-box record links are 31-bit byte offsets: beyond 2^25 interior nodes the any-hit kernel falls back to the plain node walk */
+    if (n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
     if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
     if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
     if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
