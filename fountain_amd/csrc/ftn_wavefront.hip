@@ -863,8 +863,9 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
     const uint32_t waves = grid * 4u;
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
     if (any && !count && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
-        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, knob("FTN_ANY2_POLICY", 1));
-        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, knob("FTN_ANY2_POLICY", 1));
+        const uint32_t refill2 = knob("FTN_ANY2_REFILL", refill), leaf_batch2 = knob("FTN_ANY2_LEAF_BATCH", leaf_batch);
+        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 1));
+        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 1));
         return;
     }
     lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
