@@ -74,6 +74,10 @@ struct DScene {
     const ftn_texture* textures; const ftn_material_textures* mtex; const DImage* images; const float4* texels;
     uint32_t n_textures;
     uint32_t material_types;                /* bit t set: some material has ftn_material.type == t */
+    /* scenes lit by ONE light that is an InfiniteAreaLight (the usual environment-lit scene): its record also travels in the kernel
+     * arguments, so the shading kernels specialised for it (k_wf_shade<.., ENV>) read it with scalar loads and drop the other kinds */
+    uint32_t env_only, _pad2;
+    DLight env0;
 };
 
 struct DCamera {
@@ -825,6 +829,32 @@ __device__ inline Rgb area_Le(const DLight& L, V3 n, V3 w) {     /* diffuse.rs:4
     return dot(n, w) > 0.0f ? Rgb(L.rgb[0], L.rgb[1], L.rgb[2]) : Rgb(0.0f);
 }
 struct DLiSample { Rgb radiance; V3 wi; float pdf; DSurfHit p1; };
+__device__ inline DLiSample light_sample_env(const DLight& L, const DSurfHit& ref, V2 u) {      /* infinite.rs:99-140 */
+    DLiSample s;
+    float d1, pdf1, d0, pdf0; uint32_t vi, ui;
+    dist1d_sample(L.marg_func, L.marg_cdf, L.marg_integral, L.nv, u.y, &d1, &pdf1, &vi);
+    dist1d_sample(L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), L.cond_integral[vi], L.nu, u.x, &d0, &pdf0, &ui);
+    float map_pdf = pdf0 * pdf1;
+    float theta = d1 * FTN_PI, phi = d0 * 2.0f * FTN_PI;
+    float sth, cth, sph, cph;
+    ftn_det::sincosf_det(theta, &sth, &cth); ftn_det::sincosf_det(phi, &sph, &cph);
+    s.wi = m4_vector(L.l2w, V3(sth * cph, sth * sph, cth));
+    s.pdf = (sth == 0.0f) ? 0.0f : map_pdf / (2.0f * FTN_PI * FTN_PI * sth);
+    if (map_pdf == 0.0f) s.pdf = 0.0f;                                   /* reference: unimplemented!() */
+    s.p1.p = ref.p + s.wi * (2.0f * L.world_radius); s.p1.p_err = V3(); s.p1.time = ref.time; s.p1.n = V3();
+    s.radiance = env_lookup(L, V2(d0, d1));
+    return s;
+}
+__device__ inline float light_pdf_env(const DLight& L, V3 wi) {                                  /* infinite.rs:142-154 */
+    V3 w = m4_vector(L.w2l, wi);
+    float theta = spherical_theta(w), phi = spherical_phi(w);
+    float sth = ftn_det::sinf_det(theta);
+    if (sth == 0.0f) return 0.0f;
+    float px = phi * (1.0f / (2.0f * FTN_PI)), py = theta * FTN_INV_PI;
+    long long iu = f2usize(px * (float)L.nu); if (iu > (long long)L.nu - 1) iu = (long long)L.nu - 1;
+    long long iv = f2usize(py * (float)L.nv); if (iv > (long long)L.nv - 1) iv = (long long)L.nv - 1;
+    return (L.cond_func[(size_t)iv * L.nu + iu] / L.marg_integral) / (2.0f * FTN_PI * FTN_PI * sth);
+}
 FTN_DEV_NOINLINE DLiSample light_sample(const DScene& S, const DLight& L, const DSurfHit& ref, V2 u) {
     DLiSample s;
     switch (L.kind) {
@@ -841,21 +871,7 @@ FTN_DEV_NOINLINE DLiSample light_sample(const DScene& S, const DLight& L, const 
             s.radiance = Rgb(L.rgb[0], L.rgb[1], L.rgb[2]); s.wi = d; s.pdf = 1.0f;
             return s;
         }
-        case LK_INFINITE: {                                                      /* infinite.rs:99-140 */
-            float d1, pdf1, d0, pdf0; uint32_t vi, ui;
-            dist1d_sample(L.marg_func, L.marg_cdf, L.marg_integral, L.nv, u.y, &d1, &pdf1, &vi);
-            dist1d_sample(L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), L.cond_integral[vi], L.nu, u.x, &d0, &pdf0, &ui);
-            float map_pdf = pdf0 * pdf1;
-            float theta = d1 * FTN_PI, phi = d0 * 2.0f * FTN_PI;
-            float sth, cth, sph, cph;
-            ftn_det::sincosf_det(theta, &sth, &cth); ftn_det::sincosf_det(phi, &sph, &cph);
-            s.wi = m4_vector(L.l2w, V3(sth * cph, sth * sph, cth));
-            s.pdf = (sth == 0.0f) ? 0.0f : map_pdf / (2.0f * FTN_PI * FTN_PI * sth);
-            if (map_pdf == 0.0f) s.pdf = 0.0f;                                   /* reference: unimplemented!() */
-            s.p1.p = ref.p + s.wi * (2.0f * L.world_radius); s.p1.p_err = V3(); s.p1.time = ref.time; s.p1.n = V3();
-            s.radiance = env_lookup(L, V2(d0, d1));
-            return s;
-        }
+        case LK_INFINITE: return light_sample_env(L, ref, u);
         default: {                                                               /* diffuse.rs:75-89 */
             DSurfHit ps = shape_sample(S, L.prim, u);
             s.wi = normalize(ps.p - ref.p);
@@ -869,14 +885,7 @@ FTN_DEV_NOINLINE DLiSample light_sample(const DScene& S, const DLight& L, const 
 FTN_DEV_NOINLINE float light_pdf(const DScene& S, const DLight& L, const DSurfHit& ref, V3 wi) {
     if (L.kind == LK_AREA) return shape_pdf_from_ref(S, L.prim, L.area, ref, wi);
     if (L.kind != LK_INFINITE) return 0.0f;
-    V3 w = m4_vector(L.w2l, wi);                                                 /* infinite.rs:142-154 */
-    float theta = spherical_theta(w), phi = spherical_phi(w);
-    float sth = ftn_det::sinf_det(theta);
-    if (sth == 0.0f) return 0.0f;
-    float px = phi * (1.0f / (2.0f * FTN_PI)), py = theta * FTN_INV_PI;
-    long long iu = f2usize(px * (float)L.nu); if (iu > (long long)L.nu - 1) iu = (long long)L.nu - 1;
-    long long iv = f2usize(py * (float)L.nv); if (iv > (long long)L.nv - 1) iv = (long long)L.nv - 1;
-    return (L.cond_func[(size_t)iv * L.nu + iu] / L.marg_integral) / (2.0f * FTN_PI * FTN_PI * sth);
+    return light_pdf_env(L, wi);
 }
 
 /* ------------------------------------------------------------------ RNG: rand_xoshiro 0.2.0 Xoshiro256Plus / SplitMix64, rand 0.6.5 Standard<f32> */

@@ -697,6 +697,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
     D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
+    if (lights.size() == 1 && lights[0].kind == LK_INFINITE) { D.env_only = 1; D.env0 = lights[0]; }
     sc->stack_entries = std::max<uint32_t>(hs.max_depth, 1u);
     for (const ftn_material& m : mats) if (m.type < 32u) D.material_types |= 1u << m.type;
     if ((rc = sc->stats.alloc_zero(1))) return rc;

@@ -507,7 +507,10 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 /* MT: -1 = every class in `class_mask`, material type read at run time (textured scenes);  0..4 = ONE material class, its BSDF code
  * specialised at compile time (fewer registers: 3 waves/SIMD instead of 2, 4 for mirrors);  -2 = the classes without a BSDF
  * (finished paths, misses / depth limit, null materials), the material branch compiled out. */
-template <bool TEX, int MT>
+/* ENV: the scene's only light is an InfiniteAreaLight (DScene::env_only).  Its record is read from the kernel arguments (scalar
+ * loads instead of one gather per field and lane) and the point / distant / area-light code is compiled out; every value computed
+ * is the one the generic kernel computes for such a scene. */
+template <bool TEX, int MT, bool ENV>
 __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : 3))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask) {
     const DScene& S = P.S;
     /* virtual, 256-aligned concatenation of the selected class segments: a workgroup never straddles two classes */
@@ -546,25 +549,27 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 if ((ps & PS_SHADOW) && !W.occluded[p]) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
                 if (ps & PS_MIS_ANY) {                           /* infinite light: the BSDF-sampled ray either escapes to it or contributes nothing (mod.rs:367-384) */
                     const int light_index = (int)__float_as_uint(lq.w);
-                    const DLight& Lt = S.lights[light_index];
+                    const DLight& Lt = ENV ? S.env0 : S.lights[light_index];
                     const float4 md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
                     Rgb inc(0.0f);
                     if (!W.occluded[p + W.n_paths]) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
                     if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
                 } else if (ps & PS_MIS) {
                     const int light_index = (int)__float_as_uint(lq.w);
-                    const DLight& Lt = S.lights[light_index];
+                    const DLight& Lt = ENV ? S.env0 : S.lights[light_index];
                     const DHit mh = load_hit(W, p + W.n_paths);
                     const float4 mo = W.ray[2 * (size_t)(p + W.n_paths)], md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
                     Rgb inc(0.0f);
                     if (mh.prim >= 0) {
+                      if (!ENV) {                                /* ENV: no primitive carries an area light */
                         const uint4 pi = S.prim_info[2 * mh.prim];
                         if ((int)pi.y >= 0 && (int)pi.y == light_index) {
                             DRay r0; r0.o = V3(mo.x, mo.y, mo.z); r0.d = V3(md.x, md.y, md.z); r0.t_max = FTN_INF; r0.time = 0.0f;
                             DSI s2; make_interaction(S, mh, r0, &s2);
                             inc = area_Le(Lt, s2.hit.n, -r0.d);
                         }
-                    } else if (Lt.kind == LK_INFINITE) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
+                      }
+                    } else if (ENV || Lt.kind == LK_INFINITE) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
                     if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
                 }
                 Rgb direct = Rgb(q2.x, q2.y, q2.z) * ((float)S.n_lights * radiance);
@@ -584,8 +589,11 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 DSI si;
                 if (hit) make_interaction(S, h, ray0, &si);
                 if (bounces == 0 || specular_bounce) {
-                    if (hit) { const uint4 pi = S.prim_info[2 * si.prim]; Rgb e = ((int)pi.y < 0) ? Rgb(0.0f) : area_Le(S.lights[pi.y], si.hit.n, -ray0.d); L = L + beta * e; }
-                    else L = L + beta * scene_env_Le(S, ray0.d);
+                    if (hit) {
+                        Rgb e(0.0f);
+                        if (!ENV) { const uint4 pi = S.prim_info[2 * si.prim]; if ((int)pi.y >= 0) e = area_Le(S.lights[pi.y], si.hit.n, -ray0.d); }
+                        L = L + beta * e;
+                    } else L = L + beta * (ENV ? Rgb(0.0f) + light_Le_env(S.env0, ray0.d) : scene_env_Le(S, ray0.d));
                 }
                 bool alive = true;
                 uint32_t light_word = 0;
@@ -621,12 +629,12 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                 const uint32_t nl = S.n_lights;
                                 const uint32_t ln = (uint32_t)f2usize(fmin_(rng.next() * (float)nl, (float)(nl - 1)));
                                 const V2 ul = rng.next2(), us = rng.next2();
-                                const DLight& Lt = S.lights[ln];
+                                const DLight& Lt = ENV ? S.env0 : S.lights[ln];
                                 const uint32_t flags = T_ALL & ~T_SPECULAR;
-                                const bool delta = Lt.kind == LK_POINT || Lt.kind == LK_DISTANT;
+                                const bool delta = !ENV && (Lt.kind == LK_POINT || Lt.kind == LK_DISTANT);
                                 ps |= PS_DIRECT; light_word = ln;
                                 Rgb ld(0.0f); float mis_w = 0.0f, mis_pdf = 1.0f; Rgb mis_f(0.0f);
-                                DLiSample ls = light_sample(S, Lt, si.hit, ul);
+                                DLiSample ls = ENV ? light_sample_env(Lt, si.hit, ul) : light_sample(S, Lt, si.hit, ul);
                                 if (ls.pdf > 0.0f && !ls.radiance.is_black()) {
                                     Rgb f = bsdf_f(B, si.wo, ls.wi, flags) * abs_dot(ls.wi, si.shading_n);
                                     float sp = bsdf_pdf(B, si.wo, ls.wi, flags);
@@ -645,7 +653,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                             bool go = true;
                                             if (sc.type & T_SPECULAR) mis_w = 1.0f;
                                             else {
-                                                float lp = light_pdf(S, Lt, si.hit, sc.wi);
+                                                float lp = ENV ? light_pdf_env(Lt, sc.wi) : light_pdf(S, Lt, si.hit, sc.wi);
                                                 if (lp == 0.0f) go = false; else mis_w = power_heuristic(sc.pdf, lp);
                                             }
                                             if (go) {
@@ -653,7 +661,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                                 W.ray[2 * (size_t)(p + W.n_paths)] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
                                                 W.ray[2 * (size_t)(p + W.n_paths) + 1] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
                                                 mis_f = f; mis_pdf = sc.pdf;
-                                                if (W.mis_any && Lt.kind == LK_INFINITE) { ps |= PS_MIS_ANY; push_mis_any = true; } else { ps |= PS_MIS; push_mis = true; }
+                                                if (W.mis_any && (ENV || Lt.kind == LK_INFINITE)) { ps |= PS_MIS_ANY; push_mis_any = true; } else { ps |= PS_MIS; push_mis = true; }
                                             }
                                         }
                                     }
@@ -1015,15 +1023,19 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
             {
                 const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));
-                if (P.S.n_textures != 0) hipLaunchKernelGGL((k_wf_shade<true, -1>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
-                else if (!knob("FTN_SHADE_SPECIALISE", 1)) hipLaunchKernelGGL((k_wf_shade<false, -1>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                if (P.S.n_textures != 0) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                else if (!knob("FTN_SHADE_SPECIALISE", 1)) hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
                 else {   /* one launch per material type present in the scene + one for the classes without a BSDF */
-                    hipLaunchKernelGGL((k_wf_shade<false, -2>), sgrid, dim3(256), 0, stream, P, W, in_q, 0x83u);
-                    if (P.S.material_types & 1u) hipLaunchKernelGGL((k_wf_shade<false, 0>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 2);
-                    if (P.S.material_types & 2u) hipLaunchKernelGGL((k_wf_shade<false, 1>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 3);
-                    if (P.S.material_types & 4u) hipLaunchKernelGGL((k_wf_shade<false, 2>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 4);
-                    if (P.S.material_types & 8u) hipLaunchKernelGGL((k_wf_shade<false, 3>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 5);
-                    if (P.S.material_types & 16u) hipLaunchKernelGGL((k_wf_shade<false, 4>), sgrid, dim3(256), 0, stream, P, W, in_q, 1u << 6);
+                    const bool env = P.S.env_only && knob("FTN_SHADE_ENV", 1);        /* lit by one InfiniteAreaLight: the variants specialised for it */
+#define FTN_SH(M, mask) do { if (env) hipLaunchKernelGGL((k_wf_shade<false, M, true>), sgrid, dim3(256), 0, stream, P, W, in_q, mask); \
+                             else hipLaunchKernelGGL((k_wf_shade<false, M, false>), sgrid, dim3(256), 0, stream, P, W, in_q, mask); } while (0)
+                    FTN_SH(-2, 0x83u);
+                    if (P.S.material_types & 1u) FTN_SH(0, 1u << 2);
+                    if (P.S.material_types & 2u) FTN_SH(1, 1u << 3);
+                    if (P.S.material_types & 4u) FTN_SH(2, 1u << 4);
+                    if (P.S.material_types & 8u) FTN_SH(3, 1u << 5);
+                    if (P.S.material_types & 16u) FTN_SH(4, 1u << 6);
+#undef FTN_SH
                 }
             }
             in_q ^= 1;

@@ -338,6 +338,45 @@ def test_mis_rays_through_the_any_hit_kernel_change_nothing(gpu, orc_det, monkey
     assert sto["rays_closest"] == stats["1"]["rays_closest"] and sto["rays_any"] == stats["1"]["rays_any"]
 
 
+def _env_only_scene(be, res=(96, 80)):
+    """every material the path supports, lit by ONE infinite light (rotated 16x16 map)"""
+    rng = np.random.default_rng(7)
+    b = SceneBuilder(be)
+    b.attribute_begin(); b.rotate(37.0, (0.3, 0.2, 1.0)); b.light_source("infinite", texels=(rng.random((16, 16, 3)) ** 3 * 2).astype(np.float32)); b.attribute_end()
+    b.material("matte", Kd=(0.5, 0.45, 0.4), sigma=20.0)
+    b.shape("trianglemesh", P=[(-8, -8, -1), (8, -8, -1), (8, 8, -1), (-8, 8, -1)], indices=[0, 1, 2, 0, 2, 3])
+    mats = [("matte", dict(Kd=(0.7, 0.2, 0.2))), ("mirror", dict(Kr=(0.9, 0.9, 0.9))), ("plastic", dict(Kd=(0.2, 0.5, 0.3), Ks=(0.4, 0.4, 0.4), roughness=0.1)),
+            ("metal", dict(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.05)), ("glass", dict(uroughness=0.2, vroughness=0.3, eta=1.5, remaproughness=False))]
+    for i, (name, kw) in enumerate(mats):
+        b.attribute_begin(); b.material(name, **kw); b.translate((-3.0 + 1.5 * i, 0.5 * (i % 2), 0.0)); b.shape("sphere", radius=0.7); b.attribute_end()
+    cam = PerspectiveCamera.look_at(be, (0.5, -7.0, 2.0), (0.0, 0.0, 0.0), (0, 0, 1), res, fov=45.0)
+    return b.create_scene(), cam, res
+
+
+def test_environment_only_shading_kernels_change_nothing(gpu, orc_det, monkeypatch):
+    """A scene whose only light is an InfiniteAreaLight is shaded by kernels specialised for it (light record in the kernel arguments,
+    other light kinds compiled out: DESIGN.md).  Bit-identical film and counts to the generic kernels, with the MIS rays in either
+    trace kernel, and identical to the oracle."""
+    sc, cam, res = _env_only_scene(gpu)
+    si = SamplerIntegrator(cam, PathIntegrator.new(6, 1.0))
+    films, stats = {}, {}
+    for env in ("1", "0"):
+        for mis in ("1", "0"):
+            monkeypatch.setenv("FTN_SHADE_ENV", env); monkeypatch.setenv("FTN_MIS_ANY", mis)
+            f = Film(gpu, res)
+            stats[env + mis] = si.render_parallel(sc, f, RandomSampler(4, 3, indexed=True), pipeline=WAVE)
+            films[env + mis] = f.pixels
+    monkeypatch.delenv("FTN_SHADE_ENV"); monkeypatch.delenv("FTN_MIS_ANY")
+    for k in ("10", "01", "00"):
+        assert np.array_equal(bits(films["11"]), bits(films[k])), k
+        assert all(stats["11"][c] == stats[k][c] for c in ("rays_closest", "rays_any", "camera_samples")), k
+    sco, camo, _ = _env_only_scene(orc_det)
+    fo = Film(orc_det, res)
+    sto = SamplerIntegrator(camo, PathIntegrator.new(6, 1.0)).render_parallel(sco, fo, RandomSampler(4, 3, indexed=True))
+    assert_film_equal(films["11"], fo.pixels, stats["11"]["spill_samples"], "env-only vs oracle")
+    assert sto["rays_closest"] == stats["11"]["rays_closest"] and sto["rays_any"] == stats["11"]["rays_any"]
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_specular_glass_reports_unsupported(gpu):
     b = SceneBuilder(gpu)
