@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 MEGA, WAVE = A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT
 
 
-def make_recipe(seed):
-    rng = np.random.default_rng(1000 + seed)
+def make_recipe(seed, env_only=False):
+    rng = np.random.default_rng((5000 if env_only else 1000) + seed)
     U = lambda a, b: float(rng.uniform(a, b))
     col = lambda lo=0.05, hi=0.95: tuple(float(x) for x in rng.uniform(lo, hi, 3))
     ops = []
     tex_spec, tex_float = [], []
-    if rng.random() < 0.7:
+    if rng.random() < 0.7 and not env_only:      # (textured scenes take the generic shading kernel)
         ops.append(("texture", "chk", "spectrum", "checkerboard", dict(uscale=U(1, 9), vscale=U(1, 9), tex1=col(), tex2=col()))); tex_spec.append("chk")
         ops.append(("texture", "grid", "spectrum", "uv", dict(uscale=U(0.5, 4), vscale=U(0.5, 4), udelta=U(-1, 1)))); tex_spec.append("grid")
         img = rng.random((int(rng.integers(1, 14)), int(rng.integers(1, 14)), 3)).astype(np.float32)
@@ -48,8 +48,8 @@ def make_recipe(seed):
 
     # lights
     n_expl = 0
-    for _ in range(int(rng.integers(1, 4))):
-        k = int(rng.integers(0, 3))
+    for _ in range(1 if env_only else int(rng.integers(1, 4))):
+        k = 2 if env_only else int(rng.integers(0, 3))
         if k == 0: ops.append(("light", "point", dict(I=col(5, 40), from_=tuple(float(x) for x in rng.uniform(-4, 4, 3) + np.array([0, 0, 5])))))
         elif k == 1: ops.append(("light", "distant", dict(L=col(0.5, 3), from_=tuple(float(x) for x in rng.normal(size=3) + np.array([0, 0, 2])), to=(0.0, 0.0, 0.0))))
         else:
@@ -64,7 +64,7 @@ def make_recipe(seed):
     for _ in range(int(rng.integers(4, 12))):
         ops.append(("begin",))
         ops.append(material())
-        if rng.random() < 0.25: ops.append(("area", col(2, 12)))
+        if rng.random() < 0.25 and not env_only: ops.append(("area", col(2, 12)))
         if rng.random() < 0.3: ops.append(("reverse",))
         ops.extend(xform())
         if rng.random() < 0.55:
@@ -122,7 +122,16 @@ def render(be, scene, camera, res, crop, integ, sampler, pipeline):
 
 @pytest.mark.parametrize("seed", range(24))
 def test_random_scene(gpu, orc_det, seed):
-    recipe = make_recipe(seed)
+    check_recipe(gpu, orc_det, make_recipe(seed), seed)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_environment_lit_scene(gpu, orc_det, seed):
+    """same, with ONE infinite light and no emissive shape: the scenes the environment-only shading kernels take"""
+    check_recipe(gpu, orc_det, make_recipe(seed, env_only=True), seed)
+
+
+def check_recipe(gpu, orc_det, recipe, seed):
     g = build(gpu, recipe)
     o = build(orc_det, recipe)
     assert g[0].info()["n_nodes"] == o[0].info()["n_nodes"]

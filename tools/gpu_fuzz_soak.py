@@ -1,4 +1,4 @@
-"""One-off soak: the differential fuzz of tests/test_gpu_fuzz.py over many more seeds (argv: first last)."""
+"""One-off soak: the differential fuzz of tests/test_gpu_fuzz.py over many more seeds (argv: first last [env])."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,10 +8,11 @@ from fountain_amd import default_backend
 import test_gpu_fuzz as F
 gpu, orc = default_backend(), oracle_backend(det=True)
 first, last = int(sys.argv[1]), int(sys.argv[2])
+env_only = len(sys.argv) > 3 and sys.argv[3] == "env"
 bad = 0
 for seed in range(first, last):
     try:
-        F.test_random_scene(gpu, orc, seed)
+        F.check_recipe(gpu, orc, F.make_recipe(seed, env_only=env_only), seed)
     except AssertionError as e:
         bad += 1
         print("seed %d FAILED: %s" % (seed, str(e)[:300]), flush=True)
