@@ -78,6 +78,11 @@ struct DScene {
      * arguments, so the shading kernels specialised for it (k_wf_shade<.., ENV>) read it with scalar loads and drop the other kinds */
     uint32_t env_only, _pad2;
     DLight env0;
+    /* shading records (NULL: not built): everything make_interaction needs about a primitive in ONE 128-byte line, instead of
+     * geom (48 B) + prim_info (2 x 16 B) + three normals and three uvs gathered through the vertex indices (5-9 lines for a hit at a
+     * random place of a large scene).  8 float4 per primitive: {p0, flags} {p1, material} {p2, light} {n0, uv0.x} {n1, uv0.y}
+     * {n2, uv1.x} {uv1.y, uv2.x, uv2.y, shape index} {unused}.  The traversal kernels keep reading the dense `geom`. */
+    const float4* srec;
 };
 
 struct DCamera {
@@ -90,7 +95,7 @@ struct DRay { V3 o, d; float t_max, time; };
 struct DHit { float t; int prim; float b0, b1, b2; };
 struct DSurfHit { V3 p, p_err, n; float time; };
 /* the part of SurfaceInteraction the integrator consumes */
-struct DSI { DSurfHit hit; V3 wo, shading_n, s_dpdu; int prim; };
+struct DSI { DSurfHit hit; V3 wo, shading_n, s_dpdu; int prim; int mat, light; /* material / area light of the primitive, -1 = none */ };
 /* the rest of SurfaceInteraction, only needed by textured materials: uv, geometric dpdu/dpdv, shading dndu/dndv */
 struct DSIX { V2 uv; V3 dpdu, dpdv, dndu, dndv; };
 
@@ -345,11 +350,26 @@ __device__ inline float tri_inv_det(V3 o, V3 d, V3 p0, V3 p1, V3 p2) {
     return 1.0f / (e0 + e1 + e2);
 }
 FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, float time, DSI* si, DSIX* ex = nullptr, V3 ray_o = V3(0.0f, 0.0f, 0.0f)) {
-    V3 p0, p1, p2; uint32_t fl; load_tri(S, h.prim, &p0, &p1, &p2, &fl);
-    const uint4 vi = S.prim_info[2 * h.prim + 1];
+    V3 p0, p1, p2, n0, n1, n2; uint32_t fl;
     const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
     float u0x = 0.0f, u0y = 0.0f, u1x = 1.0f, u1y = 0.0f, u2x = 1.0f, u2y = 1.0f;
-    if (fl & GF_HAS_UVS) { const float* UV = S.UV; u0x = UV[2 * vi.x]; u0y = UV[2 * vi.x + 1]; u1x = UV[2 * vi.y]; u1y = UV[2 * vi.y + 1]; u2x = UV[2 * vi.z]; u2y = UV[2 * vi.z + 1]; }
+    if (S.srec) {                                                /* one 128-byte shading record (DScene::srec) */
+        const float4* R = S.srec + 8 * (size_t)h.prim;
+        const float4 r0 = R[0], r1 = R[1], r2 = R[2];
+        p0 = V3(r0.x, r0.y, r0.z); p1 = V3(r1.x, r1.y, r1.z); p2 = V3(r2.x, r2.y, r2.z); fl = __float_as_uint(r0.w);
+        si->mat = (int)__float_as_uint(r1.w); si->light = (int)__float_as_uint(r2.w);
+        if (fl & (GF_HAS_NORMALS | GF_HAS_UVS)) {
+            const float4 r3 = R[3], r4 = R[4], r5 = R[5];
+            n0 = V3(r3.x, r3.y, r3.z); n1 = V3(r4.x, r4.y, r4.z); n2 = V3(r5.x, r5.y, r5.z);
+            if (fl & GF_HAS_UVS) { const float4 r6 = R[6]; u0x = r3.w; u0y = r4.w; u1x = r5.w; u1y = r6.x; u2x = r6.y; u2y = r6.z; }
+        }
+    } else {
+        load_tri(S, h.prim, &p0, &p1, &p2, &fl);
+        const uint4 vi = S.prim_info[2 * h.prim + 1], pi = S.prim_info[2 * h.prim];
+        si->mat = (int)pi.x; si->light = (int)pi.y;
+        if (fl & GF_HAS_UVS) { const float* UV = S.UV; u0x = UV[2 * vi.x]; u0y = UV[2 * vi.x + 1]; u1x = UV[2 * vi.y]; u1y = UV[2 * vi.y + 1]; u2x = UV[2 * vi.z]; u2y = UV[2 * vi.z + 1]; }
+        if (fl & GF_HAS_NORMALS) { const float* N = S.N; n0 = V3(N[3 * vi.x], N[3 * vi.x + 1], N[3 * vi.x + 2]); n1 = V3(N[3 * vi.y], N[3 * vi.y + 1], N[3 * vi.y + 2]); n2 = V3(N[3 * vi.z], N[3 * vi.z + 1], N[3 * vi.z + 2]); }
+    }
     float d02x = u0x - u2x, d02y = u0y - u2y, d12x = u1x - u2x, d12y = u1y - u2y;
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     float determinant = d02x * d12y - d02y * d12x;
@@ -379,8 +399,6 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
     if (fl & GF_FLIP) { n = n * -1.0f; sn = sn * -1.0f; }
     si->s_dpdu = dpdu;
     if (fl & GF_HAS_NORMALS) {
-        const float* N = S.N;
-        V3 n0(N[3 * vi.x], N[3 * vi.x + 1], N[3 * vi.x + 2]), n1(N[3 * vi.y], N[3 * vi.y + 1], N[3 * vi.y + 2]), n2(N[3 * vi.z], N[3 * vi.z + 1], N[3 * vi.z + 2]);
         V3 ns = normalize(b0 * n0 + b1 * n1 + b2 * n2);
         V3 ss = normalize(dpdu);
         V3 ts = cross(ns, ss);
@@ -405,12 +423,13 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
     si->hit.n = n; si->shading_n = sn; si->prim = h.prim;
 }
 __device__ inline bool make_interaction(const DScene& S, const DHit& h, const DRay& ray_before_hit, DSI* si, DSIX* ex = nullptr) {
-    const float4 g0 = S.geom[3 * h.prim];
+    const float4 g0 = S.srec ? S.srec[8 * (size_t)h.prim] : S.geom[3 * h.prim];
     if (__float_as_uint(g0.w) & GF_KIND_SPHERE) {
         DRay r = ray_before_hit; r.t_max = FTN_INF;   /* same root selection as at traversal time */
         float t; const float4 g1 = S.geom[3 * h.prim + 1];
         bool ok = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, si, ex);
-        si->prim = h.prim;
+        const uint4 pi = S.prim_info[2 * h.prim];
+        si->prim = h.prim; si->mat = (int)pi.x; si->light = (int)pi.y;
         return ok;
     }
     tri_interaction(S, h, ray_before_hit.d, ray_before_hit.time, si, ex, ray_before_hit.o);

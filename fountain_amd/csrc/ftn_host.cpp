@@ -530,7 +530,7 @@ struct ftn_scene {
     int device = 0;
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
-    DevBuf<float4> nodes, geom, fat; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
+    DevBuf<float4> nodes, geom, fat, srec; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
     DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
@@ -538,7 +538,7 @@ struct ftn_scene {
     WavefrontState* wf = nullptr;
     std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
-        nodes.release(); geom.release(); fat.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
+        nodes.release(); geom.release(); fat.release(); srec.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
         for (auto& b : misc4) b.release();
         textures.release(); mtex.release(); images.release(); texels.release();
@@ -610,6 +610,28 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     /* two-box record links are 31-bit byte offsets: beyond 2^25 interior nodes the any-hit kernel falls back to the plain node walk */
     if (n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
     if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
+    /* shading records (DScene::srec): one 128-byte line per primitive with everything make_interaction reads.  FTN_SREC=0: not built */
+    {
+        const char* knob = getenv("FTN_SREC");
+        if ((!knob || atoi(knob) != 0) && np != 0 && (uint64_t)np * 128u <= (16ull << 30)) {
+            std::vector<float4> rec(8 * np, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            for (size_t i = 0; i < np; i++) {
+                float4* R = &rec[8 * i];
+                const uint4 pi = info[2 * i], vi = info[2 * i + 1];
+                R[0] = geom[3 * i]; R[1] = geom[3 * i + 1]; R[2] = geom[3 * i + 2];
+                R[1].w = ftn_det::u2f(pi.x); R[2].w = ftn_det::u2f(pi.y); R[6].w = ftn_det::u2f(vi.w);
+                const uint32_t fl = ftn_det::f2u(R[0].w);
+                if (fl & GF_KIND_SPHERE) continue;
+                const uint32_t v[3] = {vi.x, vi.y, vi.z};
+                if (fl & GF_HAS_NORMALS) for (int k = 0; k < 3; k++) { R[3 + k].x = d->N[3 * (size_t)v[k]]; R[3 + k].y = d->N[3 * (size_t)v[k] + 1]; R[3 + k].z = d->N[3 * (size_t)v[k] + 2]; }
+                if (fl & GF_HAS_UVS) {
+                    R[3].w = d->UV[2 * (size_t)v[0]]; R[4].w = d->UV[2 * (size_t)v[0] + 1]; R[5].w = d->UV[2 * (size_t)v[1]];
+                    R[6].x = d->UV[2 * (size_t)v[1] + 1]; R[6].y = d->UV[2 * (size_t)v[2]]; R[6].z = d->UV[2 * (size_t)v[2] + 1];
+                }
+            }
+            if ((rc = sc->srec.upload(rec.data(), rec.size()))) return rc;
+        }
+    }
     if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
     if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
     std::vector<DSphere> sph(d->n_spheres);
@@ -695,6 +717,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
+    D.srec = sc->srec.p;
     D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
     if (lights.size() == 1 && lights[0].kind == LK_INFINITE) { D.env_only = 1; D.env0 = lights[0]; }

@@ -105,9 +105,8 @@ __device__ inline Rgb uniform_sample_one_light(Tracer<COUNT>& T, const DBsdf& B,
     return (float)nl * estimate_direct(T, B, si, us, T.S.lights[ln], (int)ln, ul);
 }
 __device__ inline Rgb emitted(const DScene& S, const DSI& si, V3 w) {          /* interaction.rs:175-180 */
-    const uint4 pi = S.prim_info[2 * si.prim];
-    if ((int)pi.y < 0) return Rgb(0.0f);
-    return area_Le(S.lights[pi.y], si.hit.n, w);
+    if (si.light < 0) return Rgb(0.0f);
+    return area_Le(S.lights[si.light], si.hit.n, w);
 }
 
 /* ------------------------------------------------------------------ PathIntegrator::incident_radiance: path.rs:25-95 */
@@ -128,7 +127,7 @@ __device__ inline Rgb path_li(Tracer<COUNT>& T, DRay ray, const DRayDiff& rd, Rn
             else L = L + beta * scene_env_Le(S, ray.d);
         }
         if (!hit || bounces >= max_depth) break;
-        const int mat = (int)S.prim_info[2 * si.prim].x;
+        const int mat = si.mat;
         if (mat >= 0) {
             DBsdf B;
             ftn_material mloc; const ftn_material* mp = &S.materials[mat];
@@ -182,7 +181,7 @@ __device__ inline Rgb direct_li(Tracer<COUNT>& T, DRay ray, DRayDiff rd, Rng& rn
         owes_t[depth] = false;
         if (!T.closest(ray, &h)) { tail = scene_env_Le(S, ray.d); have_tail = true; break; }
         DSI si; make_interaction(S, h, ray0, &si);
-        const int mat = (int)S.prim_info[2 * si.prim].x;
+        const int mat = si.mat;
         if (mat < 0) { *err = FTN_ERR_UNSUPPORTED; tail = Rgb(0.0f); have_tail = true; break; }   /* unimplemented!() :103 */
         DBsdf B;
         ftn_material mloc; const ftn_material* mp = &S.materials[mat];

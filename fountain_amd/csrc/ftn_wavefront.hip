@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 if (bounces == 0 || specular_bounce) {
                     if (hit) {
                         Rgb e(0.0f);
-                        if (!ENV) { const uint4 pi = S.prim_info[2 * si.prim]; if ((int)pi.y >= 0) e = area_Le(S.lights[pi.y], si.hit.n, -ray0.d); }
+                        if (!ENV && si.light >= 0) e = area_Le(S.lights[si.light], si.hit.n, -ray0.d);
                         L = L + beta * e;
                     } else L = L + beta * (ENV ? Rgb(0.0f) + light_Le_env(S.env0, ray0.d) : scene_env_Le(S, ray0.d));
                 }
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 if (!hit || bounces >= P.max_depth) alive = false;
                 else {
                     Rng rng; { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
-                    const int mat = (int)S.prim_info[2 * si.prim].x;
+                    const int mat = si.mat;
                     if (MT == -2 || mat < 0) {
                         DRay nr = spawn_ray(si.hit, ray0.d);                       /* null bsdf: path.rs:77-81 */
                         W.ray[2 * (size_t)(p)] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray[2 * (size_t)(p) + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
