@@ -225,6 +225,20 @@ def test_config2_sample_ranges_and_tile_shards_compose(gpu):
     assert np.all(whole.pixels[..., 3] >= 16) and whole.pixels[..., 3].sum() == 512 * 512 * 16 + (whole.pixels[..., 3] - 16).sum()
 
 
+def test_more_paths_than_one_wavefront_pass_holds(gpu):
+    """The wavefront pipeline keeps about 16 M paths in flight; 1024 x 1024 x 20 spp = 21 M camera samples takes two passes
+    (16 + 4 samples per pixel).  Same film as the megakernel, which has no passes, bit for bit."""
+    b, cam, res = scenes.cornell(gpu, res=1024)
+    sc = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    wave, mega = Film(gpu, res), Film(gpu, res)
+    st = si.render_parallel(sc, wave, RandomSampler(20, 0, indexed=True), pipeline=WAVE)
+    sm = si.render_parallel(sc, mega, RandomSampler(20, 0, indexed=True), pipeline=MEGA)
+    assert st["camera_samples"] == 1024 * 1024 * 20 == sm["camera_samples"]
+    assert st["rays_closest"] == sm["rays_closest"] and st["rays_any"] == sm["rays_any"]
+    assert_film_equal(wave.pixels, mega.pixels, st["spill_samples"], "two passes vs megakernel")
+
+
 def test_furnace_256_energy(gpu):
     """config 1 geometry at 256x256x16: the furnace value 2 - 2^-(depth) holds for every pixel without Russian roulette"""
     b, cam, res = scenes.furnace(gpu, res=256)
