@@ -810,6 +810,7 @@ struct WavefrontState {
     void* mem[32]; int n_mem = 0;
     WfBuffers W;
     hipEvent_t ev[64]; int n_ev = 0;
+    hipStream_t side = nullptr; hipEvent_t ev_ready = nullptr, ev_side = nullptr;     /* the any-hit launches run beside the closest-hit ones */
     uint32_t* host_counters = nullptr;    /* pinned */
     int n_cu = 256;
 };
@@ -821,6 +822,9 @@ void wavefront_destroy(WavefrontState* st) {
     wf_free(st);
     if (st->sort_tmp) (void)hipFree(st->sort_tmp);
     for (int i = 0; i < st->n_ev; i++) (void)hipEventDestroy(st->ev[i]);
+    if (st->ev_ready) (void)hipEventDestroy(st->ev_ready);
+    if (st->ev_side) (void)hipEventDestroy(st->ev_side);
+    if (st->side) (void)hipStreamDestroy(st->side);
     if (st->host_counters) (void)hipHostFree(st->host_counters);
     delete st;
 }
@@ -889,6 +893,13 @@ static int wf_state_init(WavefrontState** state) {
     if (*state) return FTN_OK;
     *state = new WavefrontState();
     for (int i = 0; i < 64; i++) { WF_TRY(hipEventCreate(&(*state)->ev[i])); (*state)->n_ev = i + 1; }
+    {   /* lowest priority: its workgroups should only take what the main stream's kernels leave free */
+        int least = 0, greatest = 0;
+        WF_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        WF_TRY(hipStreamCreateWithPriority(&(*state)->side, hipStreamNonBlocking, knob("FTN_WF_SIDE_PRIO", 1) ? least : 0));
+    }
+    WF_TRY(hipEventCreateWithFlags(&(*state)->ev_ready, hipEventDisableTiming));
+    WF_TRY(hipEventCreateWithFlags(&(*state)->ev_side, hipEventDisableTiming));
     WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 16 * 32 * sizeof(uint32_t)));
     hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
     (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -984,6 +995,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
     const unsigned shade_grid_max = (unsigned)st->n_cu * 8u;
     double trace_ms = 0.0; unsigned long long trace_launches = 0, mis_any_rays = 0;
+    const bool overlap = knob("FTN_WF_OVERLAP", 1) != 0;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     int ev_used = 0;
     struct Span { int a, b; };
@@ -1007,19 +1019,28 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             bool polled = false;
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
             if (ev_used + 2 > 64) { rc = flush_events(); if (rc) return rc; }
+            /* The two traces of a bounce are independent (own queues, own result arrays).  A persistent traversal kernel ends with a
+             * long drain -- the last rays are sequential walks of several hundred nodes while most waves have already left (measured:
+             * 0.3-0.8 ms from the first idle wave to the end of every launch) -- so the any-hit launch goes to a second stream and its
+             * workgroups move in as the closest-hit ones leave.  The closest-hit launch is issued first and still has the GPU to itself
+             * until it starts draining, which keeps its event timing (roofline) meaningful. */
+            const bool beside = overlap && it > 0 && q_sh == W.q_shadow;      /* (a sorted any-hit queue lives in scratch that classify reuses) */
+            if (beside) { WF_TRY(hipEventRecord(st->ev_ready, stream)); WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0)); }
             WF_TRY(hipEventRecord(st->ev[ev_used], stream));
             launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
-                launch_trace(true, count, spheres, sg, st->n_cu, lds, stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);
+                launch_trace(true, count, spheres, sg, st->n_cu, lds, beside ? st->side : stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);
+                if (beside) WF_TRY(hipEventRecord(st->ev_side, st->side));
             }
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
                 hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
                 hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
             }
+            if (beside) WF_TRY(hipStreamWaitEvent(stream, st->ev_side, 0));     /* shading needs the occlusion results (classify above did not) */
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
             {
                 const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));

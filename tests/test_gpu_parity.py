@@ -323,6 +323,25 @@ def test_ray_queue_sort_changes_nothing(gpu, monkeypatch):
         assert stats[0][k] == stats[1][k], k
 
 
+def test_any_hit_launches_beside_the_closest_hit_ones_change_nothing(gpu, monkeypatch):
+    """From the second bounce on, the any-hit trace of a bounce runs on a second (low-priority) stream beside the closest-hit trace
+    (it fills the GPU while the other kernel drains).  Same film, same counters as with one stream."""
+    b, cam, res = scenes.instanced_cubes(gpu, n_copies=27, res=(160, 160), env_n=32)
+    sc = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    films, stats = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FTN_WF_OVERLAP", flag)
+        for rep in range(2):                       # twice: the streams and events are reused from call to call
+            f = Film(gpu, res)
+            stats.append(si.render_parallel(sc, f, RandomSampler(2, 0, indexed=True), pipeline=WAVE, count_traffic=2))
+            films.append(f.pixels)
+    for k in range(1, 4):
+        assert np.array_equal(bits(films[0]), bits(films[k]))
+        for c in ("rays_closest", "rays_any", "nodes_visited", "prims_tested", "camera_samples", "mis_rays_any_hit"):
+            assert stats[0][c] == stats[k][c], c
+
+
 def test_mis_rays_through_the_any_hit_kernel_change_nothing(gpu, orc_det, monkeypatch):
     """estimate_direct's BSDF-sampled ray toward an INFINITE light only needs hit / miss (integrator/mod.rs:367-384: a hit primitive can
     only contribute if it is THIS area light), so outside the reference-order counting build it goes through the any-hit kernel.
