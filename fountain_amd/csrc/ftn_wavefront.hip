@@ -56,6 +56,7 @@ struct WfBuffers {
     uint32_t seg_cap;           /* capacity of one class segment of q_sorted */
     uint32_t* counters;         /* one 128-byte line each (CTR(i) = 32*i): 0 active A, 1 active B, 2 closest, 3 shadow, 4 head closest, 5 head shadow */
     uint32_t valid_per_sample;  /* camera samples per spp pass (sum of the tiles' pixel counts) */
+    uint32_t* drain_sig; uint32_t drain_seq, drain_at;   /* closest-hit trace: where (signal memory) and what to store once a wave finds the queue dry (NULL: nobody waits) */
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
 
@@ -238,7 +239,15 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(head + CTR(slice), chunk);
                 base = __shfl(base, 0, 64) + s_lo;
-                if (base >= s_hi) { slice = (slice + 1u) & 7u; if (++slices_done == 8u) exhausted = true; }   /* this slice is empty: help the next XCD's */
+                if (base >= s_hi) {                                       /* this slice is empty: help the next XCD's */
+                    slice = (slice + 1u) & 7u;
+                    if (++slices_done == 8u) {
+                        exhausted = true;
+                        /* the launch starts to drain: let the stream that waits for it (the any-hit trace) go ahead */
+                        if (!ANY && W.drain_sig && lane == 0 && atomicAdd(&W.counters[CTR(11)], 1u) + 1u == W.drain_at)      /* the drain_at-th wave of this launch */
+                            __hip_atomic_store(W.drain_sig, W.drain_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);          /* a timing hint only: no data is handed over */
+                    }
+                }
                 else { chunk_next = base; chunk_end = base + chunk < s_hi ? base + chunk : s_hi; }
             }
             const uint32_t avail = chunk_end - chunk_next;
@@ -717,7 +726,7 @@ __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
         W.counters[CTR(0)] = W.samples * W.valid_per_sample; W.counters[CTR(2)] = W.samples * W.valid_per_sample;
         stats->camera_samples += (unsigned long long)W.samples * W.valid_per_sample;
     } else if (mode == 1) {                                                                  /* before shade */
-        W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0;
+        W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0; W.counters[CTR(11)] = 0;
         for (int i = 16; i < 32; i++) W.counters[CTR(i)] = 0;                                /* the per-XCD queue heads of the two trace kernels */
     } else if (mode == 2) {                                                                  /* before classify */
         for (int i = 0; i < WF_NCLASS; i++) W.cls[CTR(i)] = 0;
@@ -811,6 +820,7 @@ struct WavefrontState {
     WfBuffers W;
     hipEvent_t ev[64]; int n_ev = 0;
     hipStream_t side = nullptr; hipEvent_t ev_ready = nullptr, ev_side = nullptr;     /* the any-hit launches run beside the closest-hit ones */
+    uint32_t* drain_sig = nullptr; uint32_t drain_seq = 0;                              /* signal memory for hipStreamWaitValue32 (NULL: not supported) */
     uint32_t* host_counters = nullptr;    /* pinned */
     int n_cu = 256;
 };
@@ -825,6 +835,7 @@ void wavefront_destroy(WavefrontState* st) {
     if (st->ev_ready) (void)hipEventDestroy(st->ev_ready);
     if (st->ev_side) (void)hipEventDestroy(st->ev_side);
     if (st->side) (void)hipStreamDestroy(st->side);
+    if (st->drain_sig) (void)hipFree(st->drain_sig);
     if (st->host_counters) (void)hipHostFree(st->host_counters);
     delete st;
 }
@@ -900,6 +911,14 @@ static int wf_state_init(WavefrontState** state) {
     }
     WF_TRY(hipEventCreateWithFlags(&(*state)->ev_ready, hipEventDisableTiming));
     WF_TRY(hipEventCreateWithFlags(&(*state)->ev_side, hipEventDisableTiming));
+    {   /* stream memory operations: the side stream can wait for a value a running kernel stores */
+        int dev = 0, can = 0;
+        WF_TRY(hipGetDevice(&dev));
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) {
+            if (hipExtMallocWithFlags((void**)&(*state)->drain_sig, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); (*state)->drain_sig = nullptr; }
+            else WF_TRY(hipMemset((*state)->drain_sig, 0, 8));
+        }
+    }
     WF_TRY(hipHostMalloc((void**)&(*state)->host_counters, 16 * 32 * sizeof(uint32_t)));
     hipDeviceProp_t prop; int dev = 0; WF_TRY(hipGetDevice(&dev)); WF_TRY(hipGetDeviceProperties(&prop, dev));
     (*state)->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -995,7 +1014,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
     const unsigned shade_grid_max = (unsigned)st->n_cu * 8u;
     double trace_ms = 0.0; unsigned long long trace_launches = 0, mis_any_rays = 0;
-    const bool overlap = knob("FTN_WF_OVERLAP", 1) != 0;
+    const bool overlap = knob("FTN_WF_OVERLAP", 1) != 0, drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     int ev_used = 0;
     struct Span { int a, b; };
@@ -1025,10 +1044,22 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
              * workgroups move in as the closest-hit ones leave.  The closest-hit launch is issued first and still has the GPU to itself
              * until it starts draining, which keeps its event timing (roofline) meaningful. */
             const bool beside = overlap && it > 0 && q_sh == W.q_shadow;      /* (a sorted any-hit queue lives in scratch that classify reuses) */
-            if (beside) { WF_TRY(hipEventRecord(st->ev_ready, stream)); WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0)); }
+            W.drain_sig = nullptr; W.drain_seq = 0;
+            if (beside) {
+                WF_TRY(hipEventRecord(st->ev_ready, stream)); WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0));
+                if (st->drain_sig && drain_gate) {
+                    /* ... and not before the closest-hit launch has started to drain: its first wave that finds the queue dry stores the
+                     * launch's sequence number; the write after the launch releases the waiter in any case */
+                    if (st->drain_seq >= 0xfffffff0u) { WF_TRY(hipStreamSynchronize(stream)); WF_TRY(hipStreamSynchronize(st->side)); WF_TRY(hipMemset(st->drain_sig, 0, 8)); st->drain_seq = 0; }
+                    W.drain_sig = st->drain_sig; W.drain_seq = ++st->drain_seq;
+                    W.drain_at = 1;       /* the first wave (waiting for 10-75 % of the waves to be dry measured the same) */
+                    WF_TRY(hipStreamWaitValue32(st->side, st->drain_sig, W.drain_seq, hipStreamWaitValueGte, 0xffffffffu));
+                }
+            }
             WF_TRY(hipEventRecord(st->ev[ev_used], stream));
             launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
+            if (W.drain_sig) WF_TRY(hipStreamWriteValue32(stream, st->drain_sig, W.drain_seq, 0));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
