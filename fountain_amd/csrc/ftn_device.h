@@ -134,6 +134,21 @@ __device__ inline bool slab_test(float4 nlo, float4 nhi, V3 o, V3 inv, float t_m
     const float t1 = fmin_(fmin_(fmin_(t_max, tfx), tfy), tfz);
     return !(t0 > t1);
 }
+/* same test, also handing back the clipped interval [t0, t1] (the any-hit walk orders the two children by it) */
+__device__ inline bool slab_test_node_iv(float4 a, float4 b, V3 o, V3 inv, float t_max, float* t0o, float* t1o) {
+    const float k = 1.0f + 2.0f * gamma_n(3);
+    float tnx = (a.x - o.x) * inv.x, tfx = (a.y - o.x) * inv.x;
+    float tny = (a.z - o.y) * inv.y, tfy = (a.w - o.y) * inv.y;
+    float tnz = (b.x - o.z) * inv.z, tfz = (b.y - o.z) * inv.z;
+    if (tnx > tfx) { float s = tnx; tnx = tfx; tfx = s; }
+    if (tny > tfy) { float s = tny; tny = tfy; tfy = s; }
+    if (tnz > tfz) { float s = tnz; tnz = tfz; tfz = s; }
+    tfx *= k; tfy *= k; tfz *= k;
+    const float t0 = fmax_(fmax_(fmax_(0.0f, tnx), tny), tnz);
+    const float t1 = fmin_(fmin_(fmin_(t_max, tfx), tfy), tfz);
+    *t0o = t0; *t1o = t1;
+    return !(t0 > t1);
+}
 /* keeps a loaded float4 whole: stops the compiler from splitting / sinking its dword loads behind later branches */
 __device__ inline void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 

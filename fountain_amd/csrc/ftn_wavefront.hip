@@ -403,15 +403,17 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
                     const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.fat) + cur);
                     float4 a0 = rec[0], b0 = rec[1], a1 = rec[2], b1 = rec[3];
                     pin4(a0); pin4(b0); pin4(a1); pin4(b1);
-                    const bool h0 = slab_test_node(a0, b0, o, inv, t_max), h1 = slab_test_node(a1, b1, o, inv, t_max);
+                    float i00, i01, i10, i11;
+                    const bool h0 = slab_test_node_iv(a0, b0, o, inv, t_max, &i00, &i01), h1 = slab_test_node_iv(a1, b1, o, inv, t_max, &i10, &i11);
                     const uint32_t m0 = __float_as_uint(b0.w), m1 = __float_as_uint(b1.w);
                     /* stack / next entries: byte offset of the child's record, or first primitive | bit 31 for a leaf child */
                     const uint32_t e0 = __float_as_uint(b0.z) | ((m0 >> 24) ? 0x80000000u : 0u), e1 = __float_as_uint(b1.z) | ((m1 >> 24) ? 0x80000000u : 0u);
-                    /* Which child first is a free choice here (the boolean does not depend on it).  Measured on the config-5 scene: the child
-                     * on the FAR side of the split plane first is ~2 % faster end to end than the reference's near-first order (shadow and
-                     * MIS rays start on a surface, and what blocks them tends to lie ahead rather than around the origin); leaf-child-first
-                     * and interior-child-first are slower.  policy 0 = near first. */
-                    const bool second_first = ((m0 & neg16) != 0) != (policy == 1u);
+                    /* Which child first is a free choice here (the boolean does not depend on it) and it matters: a ray that is blocked at
+                     * all ends at its first hit.  Measured on the config-5 scene, per step: reference order (near side of the split plane
+                     * first, policy 0) 34.3 ms; far side first (1) 32.1 ms -- shadow and MIS rays start on a surface, what blocks them
+                     * tends to lie ahead rather than around the origin; the child whose box the ray stays in longest first (2) 31.9 ms;
+                     * leaf-child-first, interior-child-first, shortest stay, larger entry / exit distance first: slower or equal. */
+                    const bool second_first = policy == 2u ? (i11 - i10) > (i01 - i00) : (((m0 & neg16) != 0) != (policy == 1u));
                     const uint32_t en = second_first ? e1 : e0, ef = second_first ? e0 : e1;
                     const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
                     uint32_t next = 0; bool have = true;
@@ -887,8 +889,8 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
     if (any && !count && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
         const uint32_t refill2 = knob("FTN_ANY2_REFILL", refill), leaf_batch2 = knob("FTN_ANY2_LEAF_BATCH", leaf_batch);
-        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 1));
-        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 1));
+        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 2));
+        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 2));
         return;
     }
     lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
