@@ -56,3 +56,18 @@ def test_compute_without_gpu_fails_loudly(ftn):
     with pytest.raises(FountainError) as e:
         b.create_scene()
     assert e.value.code == A.FTN_ERR_NO_DEVICE
+
+
+def test_product_sources_do_not_reach_into_the_oracle():
+    """oracle/ is test infrastructure: nothing under fountain_amd/ may include, link or load it (a product path that routes through
+    the CPU restatement would void every parity claim)."""
+    import glob, os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fountain_amd")
+    bad = []
+    for path in glob.glob(os.path.join(root, "**", "*"), recursive=True):
+        if not os.path.isfile(path) or not path.endswith((".py", ".cpp", ".h", ".hpp", ".hip", "Makefile")):
+            continue
+        text = open(path, encoding="utf-8", errors="replace").read()
+        for m in re.finditer(r'liboracle|orc_[a-z_]+\s*\(|#include\s*"[^"]*oracle|oracle_loader', text):
+            bad.append((os.path.relpath(path, root), m.group(0)))
+    assert not bad, bad
