@@ -535,6 +535,7 @@ struct ftn_scene {
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
     DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
+    bool spill_acc_dirty = true;       /* accB / accC may hold something other than zeros */
     WavefrontState* wf = nullptr;
     std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
@@ -904,12 +905,15 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     if (npix > s->acc_pixels) {
         s->accA.release(); s->accB.release(); s->accC.release();
         HIP_TRY(hipMalloc((void**)&s->accA.p, npix * sizeof(float4))); HIP_TRY(hipMalloc((void**)&s->accB.p, npix * sizeof(float4))); HIP_TRY(hipMalloc((void**)&s->accC.p, npix * sizeof(float4)));
-        s->acc_pixels = npix;
+        s->acc_pixels = npix; s->spill_acc_dirty = true;
     }
     if (sel.size() > s->tiles.n) { s->tiles.release(); HIP_TRY(hipMalloc((void**)&s->tiles.p, sel.size() * sizeof(DTile))); s->tiles.n = sel.size(); }
     HIP_TRY(hipMemsetAsync(s->accA.p, 0, npix * sizeof(float4), stream));
-    HIP_TRY(hipMemsetAsync(s->accB.p, 0, npix * sizeof(float4), stream));
-    HIP_TRY(hipMemsetAsync(s->accC.p, 0, npix * sizeof(float4), stream));
+    if (s->spill_acc_dirty) {          /* else: still all zero from the last call (DevStats::bc_writes said nothing was added) */
+        HIP_TRY(hipMemsetAsync(s->accB.p, 0, npix * sizeof(float4), stream));
+        HIP_TRY(hipMemsetAsync(s->accC.p, 0, npix * sizeof(float4), stream));
+    }
+    s->spill_acc_dirty = true;         /* until this call has finished and reported otherwise */
     HIP_TRY(hipMemsetAsync(s->stats.p, 0, sizeof(DevStats), stream));
     if (!sel.empty() && !tiles_cached) { HIP_TRY(hipMemcpyAsync(s->tiles.p, sel.data(), sel.size() * sizeof(DTile), hipMemcpyHostToDevice, stream)); memcpy(s->tile_key, key, sizeof(key)); }
     P.tiles = s->tiles.p; P.n_tiles = (uint32_t)sel.size();
@@ -926,6 +930,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     HIP_TRY(hipGetLastError());
     float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     DevStats ds; HIP_TRY(hipMemcpy(&ds, s->stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+    s->spill_acc_dirty = ds.bc_writes != 0;
     ds.rays_closest += wt.mis_any_rays; ds.rays_any -= wt.mis_any_rays;       /* they are Scene::intersect calls in the reference's accounting */
     stats_out(ds, st, ms);
     if (st) { st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; st->mis_rays_any_hit = wt.mis_any_rays; }

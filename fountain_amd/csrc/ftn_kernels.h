@@ -11,6 +11,7 @@ namespace ftn {
 
 struct DevStats {
     unsigned long long rays_closest, rays_any, nodes_visited, prims_tested, camera_samples, spill_samples, nodes_any, prims_any;
+    unsigned long long bc_writes;   /* samples added into the spill accumulators accB / accC (0: both are still all zero) */
     int error;          /* 0 or an ftn_status (NaN radiance, unsupported material) */
     int _pad;
 };
@@ -32,7 +33,7 @@ struct RenderParams {
 
 /* kernels (defined in ftn_kernels.hip) -- host-callable launchers */
 void launch_render_mega(const RenderParams& p, bool count, hipStream_t stream);
-void launch_film_resolve(const RenderParams& p, ftn_pixel* device_pixels, hipStream_t stream);
+void launch_film_resolve(const RenderParams& p, ftn_pixel* device_pixels, hipStream_t stream);   /* reads p.stats->bc_writes on the device */
 void launch_trace_batch(const DScene& S, const float* rays, size_t n, int mode /*0 closest,1 any,2 full*/, float* t_hit, int* prim,
                         float* bary, unsigned char* occluded, float* out24, DevStats* stats, uint32_t stack_entries, bool count, hipStream_t stream);
 

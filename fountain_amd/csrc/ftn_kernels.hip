@@ -27,9 +27,9 @@ __device__ inline unsigned long long wave_sum(unsigned int v) {
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     return s;
 }
-struct LaneCounters { uint32_t closest = 0, any = 0, cam = 0, spill = 0; TravCount tc{0, 0}; };
+struct LaneCounters { uint32_t closest = 0, any = 0, cam = 0, spill = 0, bc = 0; TravCount tc{0, 0}; };
 __device__ inline void flush_counters(DevStats* st, const LaneCounters& c, bool count) {
-    unsigned long long a = wave_sum(c.closest), b = wave_sum(c.any), d = wave_sum(c.cam), e = wave_sum(c.spill);
+    unsigned long long a = wave_sum(c.closest), b = wave_sum(c.any), d = wave_sum(c.cam), e = wave_sum(c.spill), f = wave_sum(c.bc);
     unsigned long long n = 0, p = 0;
     if (count) { n = wave_sum(c.tc.nodes); p = wave_sum(c.tc.prims); }
     if ((threadIdx.x & 63) == 0) {
@@ -37,6 +37,7 @@ __device__ inline void flush_counters(DevStats* st, const LaneCounters& c, bool 
         if (b) atomicAdd(&st->rays_any, b);
         if (d) atomicAdd(&st->camera_samples, d);
         if (e) atomicAdd(&st->spill_samples, e);
+        if (f) atomicAdd(&st->bc_writes, f);
         if (n) atomicAdd(&st->nodes_visited, n);
         if (p) atomicAdd(&st->prims_tested, p);
     }
@@ -268,7 +269,7 @@ __device__ inline void atomic_add4(float4* p, Rgb c, float w) {
 }
 /* Returns the number of pixels touched. own_(x,y): the pixel whose register accumulator `acc` belongs to the caller
  * (indexed mode); serial mode passes own_x = INT_MIN and writes in-tile pixels straight to A (single writer). */
-__device__ inline int film_add(const FilmCtx& F, V2 p_film, Rgb L, float sample_weight, int own_x, int own_y, float4* acc) {
+__device__ inline int film_add(const FilmCtx& F, V2 p_film, Rgb L, float sample_weight, int own_x, int own_y, float4* acc, uint32_t* bc_writes) {
     float pdx = p_film.x - 0.5f, pdy = p_film.y - 0.5f;
     int p0x = f2i_sat(ceilf(pdx - F.radius[0])), p0y = f2i_sat(ceilf(pdy - F.radius[1]));
     int p1x = f2i_sat(floorf(pdx + F.radius[0])) + 1, p1y = f2i_sat(floorf(pdy + F.radius[1])) + 1;
@@ -282,7 +283,7 @@ __device__ inline int film_add(const FilmCtx& F, V2 p_film, Rgb L, float sample_
             const bool in_tile = x >= F.sb[0] && x < F.sb[2] && y >= F.sb[1] && y < F.sb[3];
             const size_t i = film_idx(F, x, y);
             if (in_tile && own_x == FTN_OWN_SERIAL) { float4 v = F.A[i]; v.x += contrib.r; v.y += contrib.g; v.z += contrib.b; v.w += 1.0f; F.A[i] = v; }
-            else atomic_add4(in_tile ? &F.B[i] : &F.C[i], contrib, 1.0f);
+            else { atomic_add4(in_tile ? &F.B[i] : &F.C[i], contrib, 1.0f); (*bc_writes)++; }
         }
     return touched;
 }
@@ -310,7 +311,7 @@ __device__ inline void render_sample(const RenderParams& P, Tracer<COUNT>& T, co
     Rgb L = (P.integrator_kind != FTN_INTEGRATOR_PATH) ? direct_li<COUNT, TEX>(T, ray, rd, rng, P.max_depth, P.integrator_kind == FTN_INTEGRATOR_WHITTED, err)
                                                                   : path_li<COUNT, TEX>(T, ray, rd, rng, P.max_depth, P.rr_threshold, err);
     if (L.has_nans()) *err = FTN_ERR_NAN_RADIANCE;       /* check_radiance :285-287 */
-    int touched = film_add(F, p_film, L, 1.0f, own_x, own_y, acc);
+    int touched = film_add(F, p_film, L, 1.0f, own_x, own_y, acc, &T.lc.bc);
     T.lc.cam++;
     if (touched != 1) T.lc.spill++;
 }
@@ -378,11 +379,14 @@ void launch_render_mega(const RenderParams& p, bool count, hipStream_t stream) {
 
 /* ------------------------------------------------------------------ Film::merge_film_tile: film.rs:121-132.  pixel.xyz += to_xyz(tile sum) per contributing tile */
 __global__ void __launch_bounds__(256) k_film_resolve(const float4* __restrict__ A, const float4* __restrict__ B, const float4* __restrict__ C,
-                                                      ftn_pixel* __restrict__ out, size_t n) {
+                                                      ftn_pixel* __restrict__ out, size_t n, const DevStats* __restrict__ stats) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    /* no sample landed outside its own pixel (the rule with the box filter of radius 0.5): B and C are all zero, adding them changes
+     * nothing (x + 0 == x), and half of this kernel's reads can stay away */
+    const bool spilled = stats->bc_writes != 0;
     for (; i < n; i += stride) {
-        const float4 a = A[i], b = B[i], c = C[i];
+        const float4 a = A[i], zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = spilled ? B[i] : zero, c = spilled ? C[i] : zero;
         float4 o = *reinterpret_cast<const float4*>(&out[i]);
         float xyz[3];
         rgb_to_xyz(Rgb(a.x + b.x, a.y + b.y, a.z + b.z), xyz);          /* the home tile's FilmTilePixel */
@@ -398,7 +402,7 @@ void launch_film_resolve(const RenderParams& p, ftn_pixel* device_pixels, hipStr
     size_t n = (size_t)(p.crop[2] - p.crop[0]) * (size_t)(p.crop[3] - p.crop[1]);
     if (n == 0) return;
     unsigned grid = (unsigned)((n + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_film_resolve, dim3(grid), dim3(256), 0, stream, p.accA, p.accB, p.accC, device_pixels, n);
+    hipLaunchKernelGGL(k_film_resolve, dim3(grid), dim3(256), 0, stream, p.accA, p.accB, p.accC, device_pixels, n, p.stats);
 }
 
 /* ------------------------------------------------------------------ Film::into_spectrum_buffer: film.rs:195-210.  16 B in, 12 B out per pixel */

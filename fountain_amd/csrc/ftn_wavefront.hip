@@ -737,7 +737,7 @@ __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
 
 /* ------------------------------------------------------------------ accumulate: add_sample_to_tile in sample order */
 struct FilmCtxW { int crop[4]; int tpb[4]; int sb[4]; float radius[2]; };
-__device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 p_film, Rgb L, int own_x, int own_y, float4* acc, uint32_t* spill) {
+__device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 p_film, Rgb L, int own_x, int own_y, float4* acc, uint32_t* spill, uint32_t* bc_writes) {
     float pdx = p_film.x - 0.5f, pdy = p_film.y - 0.5f;
     int p0x = f2i_sat(ceilf(pdx - F.radius[0])), p0y = f2i_sat(ceilf(pdy - F.radius[1]));
     int p1x = f2i_sat(floorf(pdx + F.radius[0])) + 1, p1y = f2i_sat(floorf(pdy + F.radius[1])) + 1;
@@ -752,12 +752,13 @@ __device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 
             const bool in_tile = x >= F.sb[0] && x < F.sb[2] && y >= F.sb[1] && y < F.sb[3];
             float* f = reinterpret_cast<float*>((in_tile ? P.accB : P.accC) + ((size_t)(y - F.crop[1]) * width + (size_t)(x - F.crop[0])));
             atomicAdd(f + 0, contrib.r); atomicAdd(f + 1, contrib.g); atomicAdd(f + 2, contrib.b); atomicAdd(f + 3, 1.0f);
+            (*bc_writes)++;
         }
     if (touched != 1) (*spill)++;
 }
 __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers W) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    uint32_t spill = 0, cam = 0; int err = 0;
+    uint32_t spill = 0, bc = 0, cam = 0; int err = 0;
     if (slot < W.n_slots) {
         const DTile tile = P.tiles[slot >> 8];
         const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
@@ -776,7 +777,7 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
                 Rgb L(l.x, l.y, l.z);
                 if (L.has_nans()) err = FTN_ERR_NAN_RADIANCE;
                 const float2 pf = W.p_film[s * W.n_slots + slot];
-                wf_film_add(P, F, V2(pf.x, pf.y), L, in_crop ? px : (-2147483647), py, &acc, &spill);
+                wf_film_add(P, F, V2(pf.x, pf.y), L, in_crop ? px : (-2147483647), py, &acc, &spill, &bc);
                 cam++;
             }
             if (in_crop) P.accA[ai] = acc;
@@ -784,6 +785,7 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
     }
     (void)cam;                                               /* camera_samples is known in closed form: added once by k_wf_reset */
     if (spill) atomicAdd(&P.stats->spill_samples, (unsigned long long)spill);       /* rare */
+    if (bc) atomicAdd(&P.stats->bc_writes, (unsigned long long)bc);
     if (err) atomicCAS(&P.stats->error, 0, err);
 }
 

@@ -410,6 +410,29 @@ def test_environment_only_shading_kernels_change_nothing(gpu, orc_det, monkeypat
     assert sto["rays_closest"] == stats["11"]["rays_closest"] and sto["rays_any"] == stats["11"]["rays_any"]
 
 
+@pytest.mark.parametrize("pipeline", [WAVE, MEGA])
+def test_wide_box_filter_then_default_filter(gpu, orc_det, pipeline):
+    """BoxFilter of radius 1.25: every sample lands on 4-9 pixels, i.e. almost everything goes through the spill accumulators (float
+    atomics: sums agree to rounding, weights exactly).  Then the default radius twice on the same scene handle: the spill accumulators
+    must have been cleared after the wide render and are skipped while they are known to be clean; bit-exact both times."""
+    sc, cam, res = _env_only_scene(gpu, res=(64, 48))
+    sco, camo, _ = _env_only_scene(orc_det, res=(64, 48))
+    si, sio = SamplerIntegrator(cam, PathIntegrator.new(4, 1.0)), SamplerIntegrator(camo, PathIntegrator.new(4, 1.0))
+    for radius, exact in ((1.25, False), (0.5, True), (0.5, True)):
+        f, fo = Film(gpu, res, (0.1, 0.2, 0.9, 1.0)), Film(orc_det, res, (0.1, 0.2, 0.9, 1.0))
+        for film in (f, fo):
+            film.desc.filter_radius[0] = radius; film.desc.filter_radius[1] = radius
+        st = si.render_parallel(sc, f, RandomSampler(3, 1, indexed=True), pipeline=pipeline)
+        sto = sio.render_parallel(sco, fo, RandomSampler(3, 1, indexed=True))
+        assert st["camera_samples"] == sto["camera_samples"] and st["spill_samples"] == sto["spill_samples"]
+        assert np.array_equal(f.pixels[..., 3], fo.pixels[..., 3])                      # filter_weight_sum: whole numbers
+        if exact:
+            assert_film_equal(f.pixels, fo.pixels, st["spill_samples"], "default filter after a wide one")
+        else:
+            assert st["spill_samples"] > 0.9 * st["camera_samples"]
+            assert np.allclose(f.pixels, fo.pixels, rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_specular_glass_reports_unsupported(gpu):
     b = SceneBuilder(gpu)
