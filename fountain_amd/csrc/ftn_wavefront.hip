@@ -355,6 +355,9 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
     uint32_t mode = TM_IDLE;
     uint32_t chunk_next = 0, chunk_end = 0; bool exhausted = count == 0;
     uint32_t slice = blockIdx.x & 7u, slices_done = 0;                     /* one queue slice per XCD, see k_wf_trace */
+#ifdef FTN_DRAIN_PROBE      /* experiment build (tools/gpu_drain_probe.py): when does the first / last wave find the queue dry, when does the launch end */
+    const uint32_t t_start = (uint32_t)wall_clock64(); uint32_t t_dry = t_start; bool seen_dry = false;
+#endif
     { uint32_t c = count / (gridDim.x * 4u * 16u); c &= ~63u; chunk = c < 64u ? 64u : (c > chunk ? chunk : c); }
     uint32_t rid = 0, cur = 0, neg16 = 0, lp = 0;
     V3 o, inv, dperm; float t_max = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f; int kz = 0;
@@ -394,6 +397,9 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
             chunk_next += (need < avail ? need : avail);
         }
         const unsigned long long m_node = __ballot(mode == TM_NODE), m_leaf = __ballot(mode == TM_LEAF);
+#ifdef FTN_DRAIN_PROBE
+        if (exhausted && !seen_dry) { seen_dry = true; t_dry = (uint32_t)wall_clock64(); }
+#endif
         if ((m_node | m_leaf) == 0) { if (exhausted) break; else continue; }
         bool finish = false;
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
@@ -413,7 +419,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
                      * first, policy 0) 34.3 ms; far side first (1) 32.1 ms -- shadow and MIS rays start on a surface, what blocks them
                      * tends to lie ahead rather than around the origin; the child whose box the ray stays in longest first (2) 31.9 ms;
                      * leaf-child-first, interior-child-first, shortest stay, larger entry / exit distance first: slower or equal. */
-                    const bool second_first = policy == 2u ? (i11 - i10) > (i01 - i00) : (((m0 & neg16) != 0) != (policy == 1u));
+                    const bool second_first = (policy & 0xffu) == 2u ? (i11 - i10) > (i01 - i00) : (((m0 & neg16) != 0) != ((policy & 0xffu) == 1u));
                     const uint32_t en = second_first ? e1 : e0, ef = second_first ? e0 : e1;
                     const bool hn = second_first ? h1 : h0, hf = second_first ? h0 : h1;
                     uint32_t next = 0; bool have = true;
@@ -440,6 +446,12 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
         }
         if (finish) { W.occluded[rid] = found ? 1 : 0; mode = TM_IDLE; }
     }
+#ifdef FTN_DRAIN_PROBE
+    if (lane == 0) {
+        uint32_t* T = &W.counters[CTR(13) + 4 * ((policy >> 8) & 7u)];             /* one slot of four words per bounce */
+        atomicMax(&T[0], ~t_start); atomicMax(&T[1], ~t_dry); atomicMax(&T[2], t_dry); atomicMax(&T[3], (uint32_t)wall_clock64());
+    }
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
 }
 
@@ -725,6 +737,9 @@ __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {                                                                         /* new pass: generate fills both queues densely */
         for (int i = 0; i < 32; i++) W.counters[CTR(i)] = 0;
+#ifdef FTN_DRAIN_PROBE
+        for (int k = 0; k < 32; k++) W.counters[CTR(13) + k] = 0;
+#endif
         W.counters[CTR(0)] = W.samples * W.valid_per_sample; W.counters[CTR(2)] = W.samples * W.valid_per_sample;
         stats->camera_samples += (unsigned long long)W.samples * W.valid_per_sample;
     } else if (mode == 1) {                                                                  /* before shade */
@@ -882,6 +897,9 @@ static int sort_ray_queue(WavefrontState* st, const RenderParams& P, const WfBuf
 
 /* tuning knobs of k_wf_trace (env overrides are for experiments only) */
 
+#ifdef FTN_DRAIN_PROBE
+static uint32_t g_probe_bounce = 0;
+#endif
 static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int n_cu, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
     const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 256), node_burst = knob("FTN_TRACE_BURST", 8);
@@ -891,8 +909,12 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
     if (any && !count && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
         const uint32_t refill2 = knob("FTN_ANY2_REFILL", refill), leaf_batch2 = knob("FTN_ANY2_LEAF_BATCH", leaf_batch);
-        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 2));
-        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, knob("FTN_ANY2_POLICY", 2));
+        uint32_t policy2 = knob("FTN_ANY2_POLICY", 2);
+#ifdef FTN_DRAIN_PROBE
+        policy2 |= g_probe_bounce << 8;
+#endif
+        if (spheres) hipLaunchKernelGGL((k_wf_trace_any2<true>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, policy2);
+        else hipLaunchKernelGGL((k_wf_trace_any2<false>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill2, leaf_batch2, chunk, policy2);
         return;
     }
     lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
@@ -1047,6 +1069,9 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
              * 0.3-0.8 ms from the first idle wave to the end of every launch) -- so the any-hit launch goes to a second stream and its
              * workgroups move in as the closest-hit ones leave.  The closest-hit launch is issued first and still has the GPU to itself
              * until it starts draining, which keeps its event timing (roofline) meaningful. */
+#ifdef FTN_DRAIN_PROBE
+            g_probe_bounce = it;
+#endif
             const bool beside = overlap && it > 0 && q_sh == W.q_shadow;      /* (a sorted any-hit queue lives in scratch that classify reuses) */
             W.drain_sig = nullptr; W.drain_seq = 0;
             if (beside) {
@@ -1099,6 +1124,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 WF_TRY(hipStreamSynchronize(stream));
                 polled = true;
+#ifdef FTN_DRAIN_PROBE
+                { const uint32_t* T = &st->host_counters[CTR(13) + 4 * (it & 7u)];
+                  if (T[3]) fprintf(stderr, "[wf] any-hit launch of bounce %u: first wave dry at %.1f us, last wave dry at %.1f us, end %.1f us\n", it, (~T[1] - ~T[0]) * 0.01, (T[2] - ~T[0]) * 0.01, (T[3] - ~T[0]) * 0.01); }
+#endif
                 const size_t n = st->cap_paths;                        /* scratch: q_sorted is free until the next classify */
                 uint32_t* const k_in = W.q_sorted + 4 * n, *const k_out = W.q_sorted + 6 * n;     /* [0,2n) sorted closest, [2n,4n) sorted any-hit, keys in / out */
                 q_cl = W.q_closest; q_sh = W.q_shadow;
