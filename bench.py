@@ -5,9 +5,10 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-A STEP is one pass of the hot path over one batch of camera samples: N samples per pixel of the 4096x4096 film, with the
-film's 65,536 tiles interleaved over the N ranks -- so every GPU traces the same number of paths per step whatever N is
-(weak scaling of the 4096-spp job; `value` is the whole-job rate).  The film stays resident in HBM (a torch tensor handed to
+A STEP is one pass of the hot path over one batch of camera samples: 8 N samples per pixel of the 4096x4096 film (--spp-per-gpu 8),
+with the film's 65,536 tiles interleaved over the N ranks -- so every GPU traces the same 134 M paths per step whatever N is
+(weak scaling of the 4096-spp job; `value` is the whole-job rate).  The batch is sized for the part's memory: one wavefront of 134 M
+paths keeps ~44 GB of path state in HBM and is 15 % faster per ray than eight wavefronts of 17 M.  The film stays resident in HBM (a torch tensor handed to
 ftn_render_device by pointer); at the end of the timed region the ranks' films are summed by ONE RCCL reduce.
 Prints one JSON line on rank 0."""
 import argparse
@@ -30,6 +31,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=int(os.environ.get("FTN_BENCH_COPIES", "2309")), help="mesh copies (2309 = 10,002,588 triangles)")
     ap.add_argument("--res", type=int, default=int(os.environ.get("FTN_BENCH_RES", "4096")))
+    ap.add_argument("--spp-per-gpu", type=int, default=int(os.environ.get("FTN_BENCH_SPP_PER_GPU", "8")), help="samples per pixel one GPU renders per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=int(os.environ.get("FTN_BENCH_CPU_TILES", "96")))
     args = ap.parse_args()
@@ -69,7 +71,7 @@ def main():
     integ = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
     dev_film = torch.zeros((film.height, film.width, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    spp_per_step = world
+    spp_per_step = world * max(1, args.spp_per_gpu)
     total_spp = 4096
 
     def step(i, count=False):
@@ -142,7 +144,10 @@ def main():
                          "frac": round(achieved / 8000.0, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
                          "launches_per_step": int(launches_per_step), "rays_per_launch": int(rays_c // launches_per_step),
-                         "nodes_per_ray": round(nodes_c / max(rays_c, 1), 2), "prims_per_ray": round(prims_c / max(rays_c, 1), 3)},
+                         "nodes_per_ray": round(nodes_c / max(rays_c, 1), 2), "prims_per_ray": round(prims_c / max(rays_c, 1), 3),
+                         "note": "algorithmic bytes (32 B per node visit + 48 B per triangle test + ray i/o: SURVEY 8(d)) over the launch time; "
+                                 "most node fetches are L2 / L1 hits, so the figure can exceed the HBM peak -- `traffic` is the HBM-side byte count "
+                                 "of the same launch from PMC counters"},
         }
         # HBM-side traffic of the same kernel from PMC counters (collected offline with rocprofv3, see profiles/r01_traffic.json)
         try:

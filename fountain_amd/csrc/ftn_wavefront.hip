@@ -1026,8 +1026,11 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (n_slots == 0) return FTN_OK;
     const uint32_t total_samples = P.last_sample - P.first_sample;
     if (total_samples == 0) return FTN_OK;
-    /* samples per pass: about 16M paths in flight (fills 256 CUs for every bounce; ~6 GB of path state in HBM) */
-    uint32_t S = (uint32_t)std::max<size_t>(1, (size_t)(16u << 20) / n_slots);
+    /* samples per pass: up to 128 Mi paths in flight (~44 GB of path state and queues out of 288 GB).  Bigger wavefronts are faster per
+     * ray: the sorted queues hold more rays per cell of space (more lanes of a wave share node records) and every launch's drain --
+     * about 0.5 ms whatever its size -- is paid once for more work.  Measured on the config-5 scene, per sample per pixel: 16 Mi paths
+     * 29.7 ms, 32 Mi 27.8, 64 Mi 26.7, 128 Mi 25.7 (FTN_WF_PATHS_M, in Mi paths). */
+    uint32_t S = (uint32_t)std::max<size_t>(1, ((size_t)std::min<uint32_t>(knob("FTN_WF_PATHS_M", 128), 256u) << 20) / n_slots);
     S = std::min(S, total_samples);
     int rc = wf_reserve(st, (size_t)S * n_slots); if (rc) return rc;
     WfBuffers W = st->W;
@@ -1040,7 +1043,9 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
     const unsigned shade_grid_max = (unsigned)st->n_cu * 8u;
     double trace_ms = 0.0; unsigned long long trace_launches = 0, mis_any_rays = 0;
-    const bool overlap = knob("FTN_WF_OVERLAP", 1) != 0, drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0;
+    /* (rocprofv3's counter collection runs one dispatch at a time and never gets to the launch a stream-memory wait is waiting for:
+     * with ROCPROF_COUNTER_COLLECTION set the gate is left out -- kernels are serialised under that tool anyway) */
+    const bool overlap = knob("FTN_WF_OVERLAP", 1) != 0, drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     int ev_used = 0;
     struct Span { int a, b; };
@@ -1074,22 +1079,24 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
 #endif
             const bool beside = overlap && it > 0 && q_sh == W.q_shadow;      /* (a sorted any-hit queue lives in scratch that classify reuses) */
             W.drain_sig = nullptr; W.drain_seq = 0;
-            if (beside) {
-                WF_TRY(hipEventRecord(st->ev_ready, stream)); WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0));
-                if (st->drain_sig && drain_gate) {
-                    /* ... and not before the closest-hit launch has started to drain: its first wave that finds the queue dry stores the
-                     * launch's sequence number; the write after the launch releases the waiter in any case */
-                    if (st->drain_seq >= 0xfffffff0u) { WF_TRY(hipStreamSynchronize(stream)); WF_TRY(hipStreamSynchronize(st->side)); WF_TRY(hipMemset(st->drain_sig, 0, 8)); st->drain_seq = 0; }
-                    W.drain_sig = st->drain_sig; W.drain_seq = ++st->drain_seq;
-                    W.drain_at = 1;       /* the first wave (waiting for 10-75 % of the waves to be dry measured the same) */
-                    WF_TRY(hipStreamWaitValue32(st->side, st->drain_sig, W.drain_seq, hipStreamWaitValueGte, 0xffffffffu));
-                }
+            const bool gated = beside && st->drain_sig && drain_gate;
+            if (beside) WF_TRY(hipEventRecord(st->ev_ready, stream));
+            if (gated) {
+                /* ... and not before the closest-hit launch has started to drain: its first wave that finds the queue dry stores the
+                 * launch's sequence number; the write behind the launch releases the waiter in any case */
+                if (st->drain_seq >= 0xfffffff0u) { WF_TRY(hipStreamSynchronize(stream)); WF_TRY(hipStreamSynchronize(st->side)); WF_TRY(hipMemset(st->drain_sig, 0, 8)); st->drain_seq = 0; }
+                W.drain_sig = st->drain_sig; W.drain_seq = ++st->drain_seq;
+                W.drain_at = 1;           /* the first wave (waiting for 10-75 % of the waves to be dry measured the same) */
             }
             WF_TRY(hipEventRecord(st->ev[ev_used], stream));
             launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
             WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
-            if (W.drain_sig) WF_TRY(hipStreamWriteValue32(stream, st->drain_sig, W.drain_seq, 0));
+            if (gated) WF_TRY(hipStreamWriteValue32(stream, st->drain_sig, W.drain_seq, 0));
             spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
+            /* the side stream's waits are enqueued AFTER the launch they wait for: a tool that executes everything one command at a time
+             * in submission order (rocprofv3 --pmc) then meets launch, release, wait -- not a wait nothing can release */
+            if (beside) WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0));
+            if (gated) WF_TRY(hipStreamWaitValue32(st->side, st->drain_sig, W.drain_seq, hipStreamWaitValueGte, 0xffffffffu));
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
                 launch_trace(true, count, spheres, sg, st->n_cu, lds, beside ? st->side : stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);

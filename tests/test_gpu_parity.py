@@ -225,9 +225,11 @@ def test_config2_sample_ranges_and_tile_shards_compose(gpu):
     assert np.all(whole.pixels[..., 3] >= 16) and whole.pixels[..., 3].sum() == 512 * 512 * 16 + (whole.pixels[..., 3] - 16).sum()
 
 
-def test_more_paths_than_one_wavefront_pass_holds(gpu):
-    """The wavefront pipeline keeps about 16 M paths in flight; 1024 x 1024 x 20 spp = 21 M camera samples takes two passes
-    (16 + 4 samples per pixel).  Same film as the megakernel, which has no passes, bit for bit."""
+def test_more_paths_than_one_wavefront_pass_holds(gpu, monkeypatch):
+    """The wavefront pipeline keeps a bounded number of paths in flight (FTN_WF_PATHS_M Mi, 128 by default); with 16 Mi,
+    1024 x 1024 x 20 spp = 21 M camera samples take two passes (16 + 4 samples per pixel).  Same film as the megakernel, which has
+    no passes, bit for bit."""
+    monkeypatch.setenv("FTN_WF_PATHS_M", "16")
     b, cam, res = scenes.cornell(gpu, res=1024)
     sc = b.create_scene()
     si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
