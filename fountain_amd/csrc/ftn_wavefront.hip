@@ -35,7 +35,7 @@ enum : uint32_t { PS_BOUNCE_MASK = 0xffu, PS_SPECULAR = 1u << 8, PS_ALIVE = 1u <
 #define WF_MIS_BIT 0x80000000u
 
 struct WfBuffers {
-    uint32_t n_paths;           /* S * n_slots */
+    uint32_t n_paths;           /* n_slots * samples; path id = slot * samples + sample */
     uint32_t n_slots;           /* tiles * 256 */
     uint32_t samples;           /* S */
     uint32_t first_sample;      /* 0-based index of this pass's first sample */
@@ -113,9 +113,9 @@ __device__ inline void load_queued_ray(const WfBuffers& W, uint32_t rid, float4*
 
 /* ------------------------------------------------------------------ generate (no atomics: queue slots are known in closed form) */
 __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;          /* path id = s * n_slots + slot */
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;          /* path id = slot * samples + s: the samples of a pixel are neighbours */
     if (i >= W.n_paths) return;
-    const uint32_t slot = i % W.n_slots, s = i / W.n_slots;
+    const uint32_t slot = i / W.samples, s = i % W.samples;
     const DTile tile = P.tiles[slot >> 8];
     const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
     if (px < tile.x1 && py < tile.y1) {
@@ -131,7 +131,11 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
         W.p_film[i] = make_float2(p_film.x, p_film.y);
-        const uint32_t qi = s * W.valid_per_sample + tile.valid_off + (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
+        /* queue order = path order: tile, pixel, sample.  A wave of the first trace (and of the first shading pass, and of the shadow
+         * rays it emits) covers a few pixels instead of 64, each XCD's slice of the queue is a part of the image rather than one whole
+         * sample of it, and the path state is still read in order. */
+        const uint32_t pix = tile.valid_off + (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
+        const uint32_t qi = pix * W.samples + s;
         W.q_active[0][qi] = i;
         W.q_closest[qi] = i;
     }
@@ -634,7 +638,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                         if (TEX && material_is_textured(S, mat)) {
                             /* Texture::evaluate(si).  The differentials are the CAMERA ray's, handed on unchanged by the path integrator
                              * (path.rs:73): rebuilt here from the path's sample key instead of being carried in the path state. */
-                            const uint32_t slot = p % W.n_slots, sidx = p / W.n_slots;
+                            const uint32_t slot = p / W.samples, sidx = p % W.samples;
                             const DTile tile = P.tiles[slot >> 8];
                             const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
                             Rng crng; crng.seed(indexed_key(P.seed, px, py, W.first_sample + sidx));
@@ -771,33 +775,54 @@ __device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 
         }
     if (touched != 1) (*spill)++;
 }
+/* One thread per pixel slot adds its samples in sample order (film.rs:127-130 is order dependent in the last bit).  The samples of a
+ * slot are neighbours in memory (path id = slot * samples + s), so a thread reading its own run would touch one cache line per lane and
+ * load; the workgroup stages 8 samples of its 256 slots through LDS with coalesced loads instead. */
+#define WF_ACC_CHUNK 8u
 __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers W) {
+    __shared__ float4 s_rad[256 * WF_ACC_CHUNK];
+    __shared__ float2 s_pf[256 * WF_ACC_CHUNK];
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t spill = 0, bc = 0, cam = 0; int err = 0;
+    bool valid = false, in_crop = false; int px = 0, py = 0; size_t ai = 0;
+    FilmCtxW F; float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (slot < W.n_slots) {
         const DTile tile = P.tiles[slot >> 8];
-        const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
+        px = tile.x0 + (int)(slot & 15u); py = tile.y0 + (int)((slot >> 4) & 15u);
         if (px < tile.x1 && py < tile.y1) {
-            FilmCtxW F;
+            valid = true;
             for (int i = 0; i < 4; i++) F.crop[i] = P.crop[i];
             F.sb[0] = tile.x0; F.sb[1] = tile.y0; F.sb[2] = tile.x1; F.sb[3] = tile.y1; F.radius[0] = P.radius[0]; F.radius[1] = P.radius[1];
             int p0x = f2i_sat(ceilf((float)tile.x0 - 0.5f - P.radius[0])), p0y = f2i_sat(ceilf((float)tile.y0 - 0.5f - P.radius[1]));
             int p1x = f2i_sat(ceilf((float)tile.x1 - 0.5f + P.radius[0] + 1.0f)), p1y = f2i_sat(ceilf((float)tile.y1 - 0.5f - P.radius[1] + 1.0f));
             F.tpb[0] = max(p0x, P.crop[0]); F.tpb[1] = max(p0y, P.crop[1]); F.tpb[2] = min(p1x, P.crop[2]); F.tpb[3] = min(p1y, P.crop[3]);
-            const bool in_crop = px >= P.crop[0] && px < P.crop[2] && py >= P.crop[1] && py < P.crop[3];
-            const size_t ai = in_crop ? ((size_t)(py - P.crop[1]) * (size_t)(P.crop[2] - P.crop[0]) + (size_t)(px - P.crop[0])) : 0;
-            float4 acc = in_crop ? P.accA[ai] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            for (uint32_t s = 0; s < W.samples; s++) {
-                const float4 l = W.rad[s * W.n_slots + slot];
+            in_crop = px >= P.crop[0] && px < P.crop[2] && py >= P.crop[1] && py < P.crop[3];
+            ai = in_crop ? ((size_t)(py - P.crop[1]) * (size_t)(P.crop[2] - P.crop[0]) + (size_t)(px - P.crop[0])) : 0;
+            if (in_crop) acc = P.accA[ai];
+        }
+    }
+    const size_t block_first = (size_t)blockIdx.x * 256u * W.samples;          /* first path of this workgroup's 256 slots */
+    for (uint32_t s0 = 0; s0 < W.samples; s0 += WF_ACC_CHUNK) {
+        const uint32_t n = W.samples - s0 < WF_ACC_CHUNK ? W.samples - s0 : WF_ACC_CHUNK;
+        for (uint32_t e = threadIdx.x; e < 256u * n; e += 256u) {                /* n consecutive samples of slot e / n */
+            const uint32_t sl = e / n, k = e - sl * n;
+            const size_t p = block_first + (size_t)sl * W.samples + s0 + k;
+            if (p < W.n_paths) { s_rad[sl * WF_ACC_CHUNK + k] = W.rad[p]; s_pf[sl * WF_ACC_CHUNK + k] = W.p_film[p]; }
+        }
+        __syncthreads();
+        if (valid) {
+            for (uint32_t k = 0; k < n; k++) {
+                const float4 l = s_rad[threadIdx.x * WF_ACC_CHUNK + k];
                 Rgb L(l.x, l.y, l.z);
                 if (L.has_nans()) err = FTN_ERR_NAN_RADIANCE;
-                const float2 pf = W.p_film[s * W.n_slots + slot];
+                const float2 pf = s_pf[threadIdx.x * WF_ACC_CHUNK + k];
                 wf_film_add(P, F, V2(pf.x, pf.y), L, in_crop ? px : (-2147483647), py, &acc, &spill, &bc);
                 cam++;
             }
-            if (in_crop) P.accA[ai] = acc;
         }
+        __syncthreads();
     }
+    if (valid && in_crop) P.accA[ai] = acc;
     (void)cam;                                               /* camera_samples is known in closed form: added once by k_wf_reset */
     if (spill) atomicAdd(&P.stats->spill_samples, (unsigned long long)spill);       /* rare */
     if (bc) atomicAdd(&P.stats->bc_writes, (unsigned long long)bc);
