@@ -927,7 +927,7 @@ static uint32_t g_probe_bounce = 0;
 #endif
 static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int n_cu, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
-    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 256), node_burst = knob("FTN_TRACE_BURST", 8);
+    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 128), node_burst = knob("FTN_TRACE_BURST", 8);
     /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
