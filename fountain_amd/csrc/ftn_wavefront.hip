@@ -1057,7 +1057,13 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
      * 29.7 ms, 32 Mi 27.8, 64 Mi 26.7, 128 Mi 25.7 (FTN_WF_PATHS_M, in Mi paths). */
     uint32_t S = (uint32_t)std::max<size_t>(1, ((size_t)std::min<uint32_t>(knob("FTN_WF_PATHS_M", 128), 256u) << 20) / n_slots);
     S = std::min(S, total_samples);
-    int rc = wf_reserve(st, (size_t)S * n_slots); if (rc) return rc;
+    int rc = wf_reserve(st, (size_t)S * n_slots);
+    while (rc == FTN_ERR_OUT_OF_MEMORY && S > 1) {            /* the wavefront does not fit next to what else lives on this GPU: smaller passes */
+        wf_free(st); (void)hipGetLastError();
+        S = (S + 1) / 2;
+        rc = wf_reserve(st, (size_t)S * n_slots);
+    }
+    if (rc) { wf_free(st); return rc; }
     WfBuffers W = st->W;
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
