@@ -1076,7 +1076,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     double trace_ms = 0.0; unsigned long long trace_launches = 0, mis_any_rays = 0;
     /* (rocprofv3's counter collection runs one dispatch at a time and never gets to the launch a stream-memory wait is waiting for:
      * with ROCPROF_COUNTER_COLLECTION set the gate is left out -- kernels are serialised under that tool anyway) */
-    const bool overlap = knob("FTN_WF_OVERLAP", 1) != 0, drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
+    /* FTN_WF_OVERLAP: 0 = one stream, 1 = any-hit launches beside the closest-hit ones, 2 (default) = only for wavefronts of up to 32 Mi
+     * paths: short launches are mostly drain and gain 4 %, at 128 Mi paths the gain is 0.7 % and not worth the second stream */
+    const uint32_t overlap_mode = knob("FTN_WF_OVERLAP", 2);
+    const bool drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     int ev_used = 0;
     struct Span { int a, b; };
@@ -1108,6 +1111,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
 #ifdef FTN_DRAIN_PROBE
             g_probe_bounce = it;
 #endif
+            const bool overlap = overlap_mode == 1u || (overlap_mode == 2u && W.n_paths <= (32u << 20));
             const bool beside = overlap && it > 0 && q_sh == W.q_shadow;      /* (a sorted any-hit queue lives in scratch that classify reuses) */
             W.drain_sig = nullptr; W.drain_seq = 0;
             const bool gated = beside && st->drain_sig && drain_gate;
