@@ -2,25 +2,31 @@
  * ftn_wavefront.hip -- wavefront restructuring of PathIntegrator::incident_radiance (src/integrator/path.rs:25-95) for gfx950.
  *
  * The reference walks one path at a time: intersect -> emission -> NEE (shadow ray + MIS ray) -> BSDF sample -> RR -> loop.
- * Here a PASS renders S samples of every owned pixel at once; paths live as float4 SoA records in HBM and every bounce runs
- * these kernels over queues of path / ray ids:
+ * Here a PASS renders S samples of every owned pixel at once (one wavefront of up to 128 Mi paths, path id = slot * S + sample);
+ * paths live as float4 SoA records in HBM and every bounce runs these kernels over queues of path / ray ids:
  *
- *   k_wf_generate   get_camera_sample + generate_ray (sampler/mod.rs:43-51, camera/mod.rs:145-205); all paths -> closest queue
- *   k_wf_trace<ANY> Scene::intersect / intersect_test (bvh.rs:160-266) for a queue of rays.  Persistent 256-thread
- *                   workgroups; each wave64 pulls rays from the queue in chunks (one atomic per chunk) and re-arms idle lanes
- *                   by __ballot / __popcll ranks: lanes whose ray finished get a new one while the others keep walking.
- *                   Per-lane node stack in LDS, [level][lane] interleaved.  The queue is cut into one slice per XCD.
- *   k_wf_classify   groups the active paths by shading class (finished / missed / one per material type / null material)
- *   k_wf_shade<MT>  everything between two intersect calls of the Li loop: resolves the previous bounce's direct lighting
- *                   (shadow + MIS results), emission, termination, Material -> Bsdf, uniform_sample_one_light /
- *                   estimate_direct set-up, BSDF sampling, Russian roulette; emits shadow / MIS / continuation rays and
- *                   compacts the surviving paths into the next queue (one atomic per workgroup and queue).  One launch per
- *                   material type present, BSDF code specialised at compile time.
- *   k_wf_ray_keys + rocPRIM radix sort: orders the two ray queues by Morton(origin cell) | direction octant (coherence)
- *   k_wf_accumulate Film::add_sample_to_tile for the pass's samples of each pixel IN SAMPLE ORDER (film.rs:136-172).
+ *   k_wf_generate    get_camera_sample + generate_ray (sampler/mod.rs:43-51, camera/mod.rs:145-205); all paths -> closest queue
+ *   k_wf_trace<ANY>  Scene::intersect / intersect_test (bvh.rs:160-266) for a queue of rays.  Persistent 256-thread
+ *                    workgroups; each wave64 pulls rays from the queue in chunks (one atomic per chunk) and re-arms idle lanes
+ *                    by __ballot / __popcll ranks: lanes whose ray finished get a new one while the others keep walking.
+ *                    Per-lane node stack in LDS, [level][lane] interleaved.  The queue is cut into one slice per XCD.
+ *   k_wf_trace_any2  the production any-hit walk (shadow rays, MIS rays toward infinite lights): two boxes per step from 64-byte
+ *                    records, children in the order that ends blocked rays soonest -- a boolean does not depend on the order
+ *   k_wf_classify    groups the active paths by shading class (finished / missed / one per material type / null material)
+ *   k_wf_shade<TEX, MT, ENV>  everything between two intersect calls of the Li loop: resolves the previous bounce's direct lighting
+ *                    (shadow + MIS results), emission, termination, Material -> Bsdf, uniform_sample_one_light /
+ *                    estimate_direct set-up, BSDF sampling, Russian roulette; emits shadow / MIS / continuation rays and
+ *                    compacts the surviving paths into the next queue (one atomic per workgroup and queue).  One launch per
+ *                    material type present, BSDF code specialised at compile time; ENV: the scene's only light is an
+ *                    InfiniteAreaLight whose record travels in the kernel arguments.
+ *   k_wf_ray_keys + rocPRIM radix sort: orders the closest-hit queue by Morton(origin cell) | direction octant (coherence)
+ *   k_wf_accumulate  Film::add_sample_to_tile for the pass's samples of each pixel IN SAMPLE ORDER (film.rs:136-172).
+ *
+ * Small wavefronts (<= 32 Mi paths) run the any-hit trace of a bounce on a second stream beside the closest-hit trace.
  *
  * All per-path arithmetic and the order of the RNG draws are those of the reference (and of the megakernel), so both
- * pipelines produce identical radiance.  Dominant kernel: k_wf_trace<false>; roofline = HBM (node + triangle fetches).
+ * pipelines produce identical radiance.  Dominant kernel: k_wf_trace<false>; roofline = HBM (node + triangle fetches), in
+ * practice the L2 -> L1 gather rate.
  */
 #include "ftn_wavefront.h"
 #include "ftn_texture.h"
