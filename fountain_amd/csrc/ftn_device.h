@@ -53,6 +53,10 @@ struct DLight {
     const float* marg_cdf;                  /* [nv+1]     */
     float marg_integral; uint32_t nu, nv, _pad;
     float l2w[16], w2l[16];
+    /* every 32nd entry of each CDF, rows of (nu + 31) / 32 + 1 (conditional) and (nv + 31) / 32 + 1 (marginal) floats: 135 KB for a
+     * 1024^2 map, cache resident -- find_interval looks there first and then inside ONE 32-entry block of the 4 MB table instead of
+     * bisecting across it (NULL: a CDF was not monotone, e.g. NaN texels; the plain search is used) */
+    const float* cond_coarse; const float* marg_coarse;
 };
 
 /* one ftn_image with its MIP pyramid (mipmap.rs:78-145): level l is lw[l] x lh[l] float4 texels starting at texels[off[l]] */
@@ -840,8 +844,27 @@ __device__ inline uint32_t search_cdf(const float* cdf, uint32_t size, float u) 
     int v = (int)first - 1, hi = (int)size - 2;
     return (uint32_t)(v < 0 ? 0 : (v > hi ? hi : v));
 }
-__device__ inline void dist1d_sample(const float* func, const float* cdf, float integral, uint32_t n, float u, float* x, float* pdf, uint32_t* idx) {
-    uint32_t i = search_cdf(cdf, n + 1, u);
+/* number of elements <= u in a non-decreasing array (what the loop of search_cdf computes) */
+__device__ inline uint32_t upper_bound_f(const float* a, uint32_t size, float u) {
+    uint32_t first = 0, len = size;
+    while (len > 0) {
+        uint32_t half = len >> 1, mid = first + half;
+        if (a[mid] <= u) { first = mid + 1; len -= half + 1; } else len = half;
+    }
+    return first;
+}
+/* search_cdf through the table of every 32nd entry: same count of elements <= u, hence the same interval, for a monotone CDF */
+__device__ inline uint32_t search_cdf_blocked(const float* cdf, const float* coarse, uint32_t size, float u) {
+    const uint32_t n = size - 1u, nb = (n + 31u) >> 5;
+    uint32_t b = upper_bound_f(coarse, nb + 1u, u);
+    b = b == 0u ? 0u : b - 1u; if (b > nb - 1u) b = nb - 1u;
+    const uint32_t lo = b << 5, hi = lo + 32u < n ? lo + 32u : n;
+    const uint32_t first = (cdf[lo] <= u ? lo + 1u : lo) + (cdf[lo] <= u ? upper_bound_f(cdf + lo + 1u, hi - lo, u) : 0u);
+    int v = (int)first - 1, top = (int)size - 2;
+    return (uint32_t)(v < 0 ? 0 : (v > top ? top : v));
+}
+__device__ inline void dist1d_sample(const float* func, const float* cdf, float integral, uint32_t n, float u, float* x, float* pdf, uint32_t* idx, const float* coarse = nullptr) {
+    uint32_t i = (coarse && n > 0u) ? search_cdf_blocked(cdf, coarse, n + 1, u) : search_cdf(cdf, n + 1, u);
     float du = u - cdf[i];
     if (cdf[i + 1] - cdf[i] > 0.0f) du /= cdf[i + 1] - cdf[i];
     *pdf = func[i] / integral;
@@ -866,8 +889,9 @@ struct DLiSample { Rgb radiance; V3 wi; float pdf; DSurfHit p1; };
 __device__ inline DLiSample light_sample_env(const DLight& L, const DSurfHit& ref, V2 u) {      /* infinite.rs:99-140 */
     DLiSample s;
     float d1, pdf1, d0, pdf0; uint32_t vi, ui;
-    dist1d_sample(L.marg_func, L.marg_cdf, L.marg_integral, L.nv, u.y, &d1, &pdf1, &vi);
-    dist1d_sample(L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), L.cond_integral[vi], L.nu, u.x, &d0, &pdf0, &ui);
+    dist1d_sample(L.marg_func, L.marg_cdf, L.marg_integral, L.nv, u.y, &d1, &pdf1, &vi, L.marg_coarse);
+    dist1d_sample(L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), L.cond_integral[vi], L.nu, u.x, &d0, &pdf0, &ui,
+                  L.cond_coarse ? L.cond_coarse + (size_t)vi * (((L.nu + 31u) >> 5) + 1u) : nullptr);
     float map_pdf = pdf0 * pdf1;
     float theta = d1 * FTN_PI, phi = d0 * 2.0f * FTN_PI;
     float sth, cth, sph, cph;

@@ -709,6 +709,23 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if ((rc = b4.upload(cint.data(), cint.size()))) return rc;             /* marginal func == conditional integrals */
             if ((rc = b5.upload(mcdf.data(), mcdf.size()))) return rc;
             L.texels = b0.p; L.cond_func = b1.p; L.cond_cdf = b2.p; L.cond_integral = b3.p; L.marg_func = b4.p; L.marg_cdf = b5.p;
+            {   /* every 32nd CDF entry (DLight::cond_coarse / marg_coarse); only for CDFs that really are non-decreasing */
+                bool monotone = true;
+                auto check = [&](const float* c, uint32_t n) { for (uint32_t k = 0; k < n; k++) if (!(c[k] <= c[k + 1])) monotone = false; };
+                for (uint32_t v2 = 0; v2 < nv; v2++) check(&ccdf[(size_t)v2 * (nu + 1)], nu);
+                check(mcdf.data(), nv);
+                if (monotone && !getenv("FTN_NO_COARSE_CDF")) {
+                    const uint32_t nbu = (nu + 31u) / 32u, nbv = (nv + 31u) / 32u;
+                    std::vector<float> cc((size_t)nv * (nbu + 1)), mc(nbv + 1);
+                    for (uint32_t v2 = 0; v2 < nv; v2++) for (uint32_t k = 0; k <= nbu; k++) cc[(size_t)v2 * (nbu + 1) + k] = ccdf[(size_t)v2 * (nu + 1) + std::min(k * 32u, nu)];
+                    for (uint32_t k = 0; k <= nbv; k++) mc[k] = mcdf[std::min(k * 32u, nv)];
+                    DevBuf<float> b6, b7;
+                    if ((rc = b6.upload(cc.data(), cc.size()))) return rc;
+                    if ((rc = b7.upload(mc.data(), mc.size()))) return rc;
+                    L.cond_coarse = b6.p; L.marg_coarse = b7.p;
+                    sc->misc.push_back(b6); sc->misc.push_back(b7);
+                }
+            }
             sc->misc4.push_back(b0); sc->misc.push_back(b1); sc->misc.push_back(b2); sc->misc.push_back(b3); sc->misc.push_back(b4); sc->misc.push_back(b5);
         }
     }
