@@ -5,10 +5,10 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-A STEP is one pass of the hot path over one batch of camera samples: 8 N samples per pixel of the 4096x4096 film (--spp-per-gpu 8),
-with the film's 65,536 tiles interleaved over the N ranks -- so every GPU traces the same 134 M paths per step whatever N is
-(weak scaling of the 4096-spp job; `value` is the whole-job rate).  The batch is sized for the part's memory: one wavefront of 134 M
-paths keeps ~44 GB of path state in HBM and is 15 % faster per ray than eight wavefronts of 17 M.  The film stays resident in HBM (a torch tensor handed to
+A STEP is one pass of the hot path over one batch of camera samples: 16 N samples per pixel of the 4096x4096 film (--spp-per-gpu 16),
+with the film's 65,536 tiles interleaved over the N ranks -- so every GPU traces the same 268 M paths per step whatever N is
+(weak scaling of the 4096-spp job; `value` is the whole-job rate).  The batch is sized for the part's memory: one wavefront of 268 M
+paths keeps ~88 GB of path state in HBM and is 18 % faster per ray than sixteen wavefronts of 17 M.  The film stays resident in HBM (a torch tensor handed to
 ftn_render_device by pointer); at the end of the timed region the ranks' films are summed by ONE RCCL reduce.
 Prints one JSON line on rank 0."""
 import argparse
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=int(os.environ.get("FTN_BENCH_COPIES", "2309")), help="mesh copies (2309 = 10,002,588 triangles)")
     ap.add_argument("--res", type=int, default=int(os.environ.get("FTN_BENCH_RES", "4096")))
-    ap.add_argument("--spp-per-gpu", type=int, default=int(os.environ.get("FTN_BENCH_SPP_PER_GPU", "8")), help="samples per pixel one GPU renders per step")
+    ap.add_argument("--spp-per-gpu", type=int, default=int(os.environ.get("FTN_BENCH_SPP_PER_GPU", "16")), help="samples per pixel one GPU renders per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=int(os.environ.get("FTN_BENCH_CPU_TILES", "96")))
     args = ap.parse_args()

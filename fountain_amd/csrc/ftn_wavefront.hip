@@ -2,7 +2,7 @@
  * ftn_wavefront.hip -- wavefront restructuring of PathIntegrator::incident_radiance (src/integrator/path.rs:25-95) for gfx950.
  *
  * The reference walks one path at a time: intersect -> emission -> NEE (shadow ray + MIS ray) -> BSDF sample -> RR -> loop.
- * Here a PASS renders S samples of every owned pixel at once (one wavefront of up to 128 Mi paths, path id = slot * S + sample);
+ * Here a PASS renders S samples of every owned pixel at once (one wavefront of up to 256 Mi paths, path id = slot * S + sample);
  * paths live as float4 SoA records in HBM and every bounce runs these kernels over queues of path / ray ids:
  *
  *   k_wf_generate    get_camera_sample + generate_ray (sampler/mod.rs:43-51, camera/mod.rs:145-205); all paths -> closest queue
@@ -1057,11 +1057,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (n_slots == 0) return FTN_OK;
     const uint32_t total_samples = P.last_sample - P.first_sample;
     if (total_samples == 0) return FTN_OK;
-    /* samples per pass: up to 128 Mi paths in flight (~44 GB of path state and queues out of 288 GB).  Bigger wavefronts are faster per
-     * ray: the sorted queues hold more rays per cell of space (more lanes of a wave share node records) and every launch's drain --
-     * about 0.5 ms whatever its size -- is paid once for more work.  Measured on the config-5 scene, per sample per pixel: 16 Mi paths
-     * 29.7 ms, 32 Mi 27.8, 64 Mi 26.7, 128 Mi 25.7 (FTN_WF_PATHS_M, in Mi paths). */
-    uint32_t S = (uint32_t)std::max<size_t>(1, ((size_t)std::min<uint32_t>(knob("FTN_WF_PATHS_M", 128), 256u) << 20) / n_slots);
+    /* samples per pass: up to 256 Mi paths in flight (~88 GB of path state and queues out of 288 GB; the ids, queue indices and sort
+     * counts are 32-bit: 2^28 paths is also their limit).  Bigger wavefronts are faster per ray: the sorted queues hold more rays per
+     * cell of space (more lanes of a wave share node records) and every launch's drain -- about 0.5 ms whatever its size -- is paid
+     * once for more work.  Measured on the config-5 scene, per sample per pixel: 16 Mi paths 29.7 ms, 32 Mi 27.8, 64 Mi 26.7,
+     * 128 Mi 25.1, 256 Mi 24.5 (FTN_WF_PATHS_M, in Mi paths).  If the GPU has less to give, the pass is halved (below). */
+    uint32_t S = (uint32_t)std::max<size_t>(1, ((size_t)std::min<uint32_t>(knob("FTN_WF_PATHS_M", 256), 256u) << 20) / n_slots);
     S = std::min(S, total_samples);
     int rc = wf_reserve(st, (size_t)S * n_slots);
     while (rc == FTN_ERR_OUT_OF_MEMORY && S > 1) {            /* the wavefront does not fit next to what else lives on this GPU: smaller passes */
