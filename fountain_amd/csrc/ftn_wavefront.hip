@@ -1057,6 +1057,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (n_slots == 0) return FTN_OK;
     const uint32_t total_samples = P.last_sample - P.first_sample;
     if (total_samples == 0) return FTN_OK;
+    if (tiles.size() > ((size_t)1 << 20)) { g_wf_err = "more than 2^20 tiles (2^28 pixel slots) in one call: render the film in several tile ranges"; return FTN_ERR_UNSUPPORTED; }
     /* samples per pass: up to 256 Mi paths in flight (~88 GB of path state and queues out of 288 GB; the ids, queue indices and sort
      * counts are 32-bit: 2^28 paths is also their limit).  Bigger wavefronts are faster per ray: the sorted queues hold more rays per
      * cell of space (more lanes of a wave share node records) and every launch's drain -- about 0.5 ms whatever its size -- is paid
