@@ -1154,18 +1154,22 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
             {
                 const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));
-                if (P.S.n_textures != 0) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
-                else if (!knob("FTN_SHADE_SPECIALISE", 1)) hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
-                else {   /* one launch per material type present in the scene + one for the classes without a BSDF */
+                const bool tex = P.S.n_textures != 0;
+                if (!knob("FTN_SHADE_SPECIALISE", 1)) {
+                    if (tex) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                    else hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                } else {   /* one launch per material type present in the scene + one for the classes without a BSDF */
                     const bool env = P.S.env_only && knob("FTN_SHADE_ENV", 1);        /* lit by one InfiniteAreaLight: the variants specialised for it */
-#define FTN_SH(M, mask) do { if (env) hipLaunchKernelGGL((k_wf_shade<false, M, true>), sgrid, dim3(256), 0, stream, P, W, in_q, mask); \
-                             else hipLaunchKernelGGL((k_wf_shade<false, M, false>), sgrid, dim3(256), 0, stream, P, W, in_q, mask); } while (0)
+#define FTN_SH2(T, M, E, mask) hipLaunchKernelGGL((k_wf_shade<T, M, E>), sgrid, dim3(256), 0, stream, P, W, in_q, mask)
+#define FTN_SH(M, mask) do { if (tex) { if (env) FTN_SH2(true, M, true, mask); else FTN_SH2(true, M, false, mask); } \
+                             else { if (env) FTN_SH2(false, M, true, mask); else FTN_SH2(false, M, false, mask); } } while (0)
                     FTN_SH(-2, 0x83u);
                     if (P.S.material_types & 1u) FTN_SH(0, 1u << 2);
                     if (P.S.material_types & 2u) FTN_SH(1, 1u << 3);
                     if (P.S.material_types & 4u) FTN_SH(2, 1u << 4);
                     if (P.S.material_types & 8u) FTN_SH(3, 1u << 5);
                     if (P.S.material_types & 16u) FTN_SH(4, 1u << 6);
+#undef FTN_SH2
 #undef FTN_SH
                 }
             }
