@@ -933,13 +933,13 @@ static uint32_t g_probe_bounce = 0;
 #endif
 static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int n_cu, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
-    const uint32_t refill = knob("FTN_TRACE_REFILL", 16), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 128), node_burst = knob("FTN_TRACE_BURST", 8);
+    const uint32_t refill = knob("FTN_TRACE_REFILL", 24), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 128), node_burst = knob("FTN_TRACE_BURST", 8);
     /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
     if (any && !count && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
-        const uint32_t refill2 = knob("FTN_ANY2_REFILL", refill), leaf_batch2 = knob("FTN_ANY2_LEAF_BATCH", leaf_batch);
+        const uint32_t refill2 = knob("FTN_ANY2_REFILL", 16), leaf_batch2 = knob("FTN_ANY2_LEAF_BATCH", leaf_batch);
         uint32_t policy2 = knob("FTN_ANY2_POLICY", 2);
 #ifdef FTN_DRAIN_PROBE
         policy2 |= g_probe_bounce << 8;
