@@ -878,13 +878,19 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
                       const ftn_tile_range* tr, const ftn_render_options* opt, void* device_pixels, void* stream_v, ftn_stats* st) {
     if (!cs || !cam || !film || !sd || !id || !device_pixels) return fail(FTN_ERR_INVALID_ARGUMENT, "null argument");
     ftn_scene* s = const_cast<ftn_scene*>(cs);
+    /* the scene's arrays live on the device it was created on: a different device in the options would launch with foreign pointers */
+    if (opt && opt->device >= 0 && s->device >= 0 && opt->device != s->device) return fail(FTN_ERR_INVALID_ARGUMENT, "ftn_render_options.device differs from the device the scene was created on");
     int rc = set_device(opt && opt->device >= 0 ? opt->device : s->device); if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_v;
     const bool indexed = sd->kind == FTN_SAMPLER_INDEXED;
+    /* sample range [first_sample, first_sample + sample_count) must lie inside [0, samples_per_pixel] (64-bit: no wrap-around) */
+    if (indexed && ((uint64_t)sd->first_sample > (uint64_t)sd->samples_per_pixel || (uint64_t)sd->first_sample + (uint64_t)sd->sample_count > (uint64_t)sd->samples_per_pixel))
+        return fail(FTN_ERR_INVALID_ARGUMENT, "sample range outside [0, samples_per_pixel]");
     if (!indexed && sd->kind != FTN_SAMPLER_TILE_SERIAL) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown sampler kind");
     if (!indexed && (sd->first_sample != 0 || (sd->sample_count != 0 && sd->sample_count != sd->samples_per_pixel)))
         return fail(FTN_ERR_INVALID_ARGUMENT, "sample ranges need FTN_SAMPLER_INDEXED");
     if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING && id->kind != FTN_INTEGRATOR_WHITTED) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
+    if (id->max_depth > 65535u) return fail(FTN_ERR_INVALID_ARGUMENT, "max_depth is a u16 in the reference (integrator/path.rs:14)");
     uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
     if (pipeline == FTN_PIPELINE_AUTO) pipeline = (indexed && id->kind == FTN_INTEGRATOR_PATH) ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
     if (pipeline == FTN_PIPELINE_WAVEFRONT && (!indexed || id->kind != FTN_INTEGRATOR_PATH))
@@ -898,6 +904,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
                        (int32_t)first, (int32_t)stride, (int32_t)cnt, 1};
     const bool tiles_cached = memcmp(key, s->tile_key, sizeof(key)) == 0;
     if (!tiles_cached) {
+        memset(s->tile_key, 0, sizeof(s->tile_key));      /* the host list is about to change: no key is valid until list AND device copy are in place */
         std::vector<DTile> all; list_tiles(film, &all);
         s->sel.clear();
         for (size_t i = first, k = 0; i < all.size() && (cnt == 0 || k < cnt); i += stride, k++) s->sel.push_back(all[i]);
@@ -932,20 +939,27 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     }
     s->spill_acc_dirty = true;         /* until this call has finished and reported otherwise */
     HIP_TRY(hipMemsetAsync(s->stats.p, 0, sizeof(DevStats), stream));
-    if (!sel.empty() && !tiles_cached) { HIP_TRY(hipMemcpyAsync(s->tiles.p, sel.data(), sel.size() * sizeof(DTile), hipMemcpyHostToDevice, stream)); memcpy(s->tile_key, key, sizeof(key)); }
+    if (!tiles_cached) {
+        if (!sel.empty()) HIP_TRY(hipMemcpyAsync(s->tiles.p, sel.data(), sel.size() * sizeof(DTile), hipMemcpyHostToDevice, stream));
+        memcpy(s->tile_key, key, sizeof(key));            /* (an empty selection is a valid cached state too) */
+    }
     P.tiles = s->tiles.p; P.n_tiles = (uint32_t)sel.size();
     P.accA = s->accA.p; P.accB = s->accB.p; P.accC = s->accC.p; P.stats = s->stats.p;
 
-    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
+    struct EventPair {                                    /* destroyed on every way out */
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, stream));
     WavefrontTimes wt; memset(&wt, 0, sizeof(wt));
     if (pipeline == FTN_PIPELINE_WAVEFRONT) { rc = wavefront_render(&s->wf, P, sel, count, stream, &wt, count_production); if (rc) return fail(rc, wavefront_error()); }
     else launch_render_mega(P, count, stream);
     launch_film_resolve(P, (ftn_pixel*)device_pixels, stream);
-    HIP_TRY(hipEventRecord(e1, stream));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(ev.b, stream));
+    HIP_TRY(hipEventSynchronize(ev.b));
     HIP_TRY(hipGetLastError());
-    float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, ev.a, ev.b);
     DevStats ds; HIP_TRY(hipMemcpy(&ds, s->stats.p, sizeof(ds), hipMemcpyDeviceToHost));
     s->spill_acc_dirty = ds.bc_writes != 0;
     ds.rays_closest += wt.mis_any_rays; ds.rays_any -= wt.mis_any_rays;       /* they are Scene::intersect calls in the reference's accounting */

@@ -37,7 +37,8 @@
 namespace ftn {
 
 /* pstate bits */
-enum : uint32_t { PS_BOUNCE_MASK = 0xffu, PS_SPECULAR = 1u << 8, PS_ALIVE = 1u << 9, PS_DIRECT = 1u << 10, PS_SHADOW = 1u << 11, PS_MIS = 1u << 12, PS_DELTA = 1u << 13, PS_MIS_ANY = 1u << 14 /* the MIS ray went through the any-hit kernel */ };
+/* the bounce count takes 16 bits: PathIntegrator::max_depth is a u16 in the reference (path.rs:14), and ftn_render_device refuses more */
+enum : uint32_t { PS_BOUNCE_MASK = 0xffffu, PS_SPECULAR = 1u << 16, PS_ALIVE = 1u << 17, PS_DIRECT = 1u << 18, PS_SHADOW = 1u << 19, PS_MIS = 1u << 20, PS_DELTA = 1u << 21, PS_MIS_ANY = 1u << 22 /* the MIS ray went through the any-hit kernel */ };
 #define WF_MIS_BIT 0x80000000u
 
 struct WfBuffers {
@@ -907,7 +908,16 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     return FTN_OK;
 }
 
-static uint32_t knob(const char* name, uint32_t def) { const char* v = getenv(name); return v ? (uint32_t)atoi(v) : def; }
+/* tuning knobs (environment overrides, for experiments only): the environment is read once per entry-point call (knobs_begin), not
+ * once per launch of the bounce loop */
+#include <unordered_map>
+static thread_local std::unordered_map<std::string, std::pair<bool, uint32_t>> g_knobs;
+static void knobs_begin() { g_knobs.clear(); }
+static uint32_t knob(const char* name, uint32_t def) {
+    auto it = g_knobs.find(name);
+    if (it == g_knobs.end()) { const char* v = getenv(name); it = g_knobs.emplace(name, std::make_pair(v != nullptr, v ? (uint32_t)atoi(v) : 0u)).first; }
+    return it->second.first ? it->second.second : def;
+}
 
 /* sorts queue[0, cnt) by the rays' coherence keys into `out`; *sorted_q = out (or the queue itself when it is too short to bother) */
 static int sort_ray_queue(WavefrontState* st, const RenderParams& P, const WfBuffers& W, bool any, uint32_t* queue, uint32_t cnt, uint32_t* out,
@@ -1019,6 +1029,7 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
                           float* t_hit, int* prim, float* bary, unsigned char* occluded, float* out24, DevStats* stats, hipStream_t stream) {
     if (n_rays == 0) return FTN_OK;
     if (n_rays >= (1ull << 31)) { g_wf_err = "too many rays in one batch"; return FTN_ERR_INVALID_ARGUMENT; }
+    knobs_begin();
     int rc = wf_state_init(state); if (rc) return rc;
     WavefrontState* st = *state;
     const uint32_t n = (uint32_t)n_rays;
@@ -1050,6 +1061,7 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
 
 int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times,
                      bool count_production) {
+    knobs_begin();
     { int rc0 = wf_state_init(state); if (rc0) return rc0; }
     WavefrontState* st = *state;
     RenderParams P = P0;
@@ -1106,7 +1118,9 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
         hipLaunchKernelGGL(k_wf_generate, dim3((W.n_paths + 255) / 256), dim3(256), 0, stream, P, W);
         int in_q = 0;
         const uint32_t* q_cl = W.q_closest; const uint32_t* q_sh = W.q_shadow;      /* the camera rays' queue is in pixel order already */
-        const uint32_t max_iter = P.max_depth + 2 + 64;     /* +64: null-material pass-throughs do not count as bounces */
+        /* null-material pass-throughs do not count as bounces (path.rs:77-81), so the number of rounds has no bound in max_depth alone: the
+         * loop ends when a poll finds no active path; the cap only guards against a path that never terminates */
+        const uint32_t max_iter = P.max_depth + 2 + (1u << 20);
         for (uint32_t it = 0; it < max_iter; it++) {
             bool polled = false;
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);

@@ -179,6 +179,8 @@ int orc_render(const orc_scene* s, const ftn_camera_desc* cam, const ftn_film_de
     Integrator it{id->kind, id->max_depth, id->rr_threshold};
     Sampler base; base.kind = sd->kind; base.base_seed = sd->seed; base.samples_per_pixel = sd->samples_per_pixel;
     base.rng = Xoshiro256Plus::seed_from_u64(sd->seed);
+    if (sd->kind == FTN_SAMPLER_INDEXED && ((uint64_t)sd->first_sample > (uint64_t)sd->samples_per_pixel || (uint64_t)sd->first_sample + (uint64_t)sd->sample_count > (uint64_t)sd->samples_per_pixel))
+        return fail(FTN_ERR_INVALID_ARGUMENT, "sample range outside [0, samples_per_pixel]");     /* same contract as ftn_render_device */
     base.first_sample = sd->first_sample;
     base.last_sample = sd->first_sample + (sd->sample_count ? sd->sample_count : (sd->samples_per_pixel - sd->first_sample));
     if (sd->kind == FTN_SAMPLER_TILE_SERIAL && (sd->first_sample != 0 || (sd->sample_count != 0 && sd->sample_count != sd->samples_per_pixel)))

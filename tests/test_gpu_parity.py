@@ -463,3 +463,36 @@ def test_null_material_pass_through(gpu, orc_det):
         (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, make, PathIntegrator.new(3, 1.0), RandomSampler(4, 0, indexed=True), pl)
         assert_film_equal(px, pxo, st["spill_samples"], "null material")
         assert st["rays_closest"] == sto["rays_closest"]
+
+
+# ------------------------------------------------------------------ round-1 review findings
+@pytest.mark.parametrize("pipeline", [MEGA, WAVE])
+def test_tile_selection_cache_full_empty_full(gpu, pipeline):
+    """full film, then a tile range that selects nothing, then the full film again on the SAME scene handle: the third call must
+    render what the first did (the cached tile list used to survive the empty call under the old key)."""
+    b, cam, res = scenes.cornell(gpu, res=48)
+    scene = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator(3, 1.0))
+    smp = RandomSampler(2, 0, indexed=True)
+    films = []
+    for tiles in (None, (1000, 1, 1000), None, (2, 3, 2), None):
+        film = Film(gpu, res)
+        st = si.render_parallel(scene, film, smp, tiles=tiles, pipeline=pipeline)
+        films.append((film.pixels.copy(), st))
+    assert films[1][1]["camera_samples"] == 0 and not films[1][0].any()
+    assert films[0][1]["camera_samples"] == 48 * 48 * 2
+    for k in (2, 4):
+        assert films[k][1]["camera_samples"] == films[0][1]["camera_samples"]
+        assert np.array_equal(bits(films[k][0]), bits(films[0][0]))
+    assert films[3][1]["camera_samples"] == 2 * 256 * 2
+
+
+def test_wavefront_paths_deeper_than_255_bounces(gpu, orc_det):
+    """max_depth 300, no Russian roulette, albedo-0.5 furnace: paths run the full 300 bounces; the wavefront's bounce counter used to
+    be 8 bits wide.  Bit-exact against the oracle and the megakernel."""
+    integ, smp = PathIntegrator(300, 0.0), RandomSampler(2, 0, indexed=True)
+    (rg, pg, sg), (ro, po, so) = render_pair(gpu, orc_det, lambda be: scenes.furnace(be, res=16), integ, smp, WAVE)
+    assert sg["rays_closest"] == so["rays_closest"] and sg["rays_closest"] >= 16 * 16 * 2 * 300
+    assert_film_equal(pg, po, sg["spill_samples"], "furnace, depth 300")
+    with pytest.raises(FountainError):
+        scenes.render(gpu, *scenes.furnace(gpu, res=16), PathIntegrator(70000, 0.0), smp, backend_kwargs=dict(pipeline=WAVE))

@@ -81,3 +81,53 @@ def test_null_arrays_are_refused(ftn):
     d2, keep2 = base(ftn)
     d2.materials[0].type = 11
     assert bvh_build(ftn, d2) == A.FTN_ERR_INVALID_ARGUMENT
+
+
+# ------------------------------------------------------------------ render arguments (sample ranges are validated at the ABI)
+BAD_RANGES = [(17, 0), (4, 13), (0, 17), (0xFFFFFFFF, 2), (16, 1)]          # (first_sample, sample_count) at 16 spp
+GOOD_RANGES = [(0, 0), (0, 16), (15, 1), (16, 0), (3, 5)]
+
+
+def _render_range(be, first, count, **kw):
+    from fountain_amd import Film, PathIntegrator, RandomSampler, SamplerIntegrator, scenes
+    b, cam, res = scenes.furnace(be, res=16)
+    scene = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator(3, 1.0))
+    film = Film(be, res)
+    return si.render_parallel(scene, film, RandomSampler(16, 0, indexed=True, first_sample=first, sample_count=count), tiles=(0, 1, 1), **kw), film
+
+
+@pytest.mark.parametrize("first,count", BAD_RANGES)
+def test_oracle_refuses_sample_ranges_outside_the_pixel_samples(orc, first, count):
+    from fountain_amd.api import FountainError
+    with pytest.raises(FountainError) as e:
+        _render_range(orc, first, count)
+    assert e.value.code == A.FTN_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("first,count", GOOD_RANGES)
+def test_oracle_accepts_sample_ranges_inside_the_pixel_samples(orc, first, count):
+    st, film = _render_range(orc, first, count)
+    want = (16 - first) if count == 0 else count
+    assert st["camera_samples"] == 256 * want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT])
+def test_gpu_refuses_sample_ranges_outside_the_pixel_samples(gpu, pipeline):
+    from fountain_amd.api import FountainError
+    for first, count in BAD_RANGES:
+        with pytest.raises(FountainError) as e:
+            _render_range(gpu, first, count, pipeline=pipeline)
+        assert e.value.code == A.FTN_ERR_INVALID_ARGUMENT, (first, count)
+    for first, count in GOOD_RANGES:
+        st, film = _render_range(gpu, first, count, pipeline=pipeline)
+        assert st["camera_samples"] == 256 * ((16 - first) if count == 0 else count)
+
+
+@pytest.mark.gpu
+def test_gpu_refuses_a_device_other_than_the_scenes(gpu):
+    from fountain_amd.api import FountainError
+    with pytest.raises(FountainError) as e:
+        _render_range(gpu, 0, 0, device=5)
+    assert e.value.code == A.FTN_ERR_INVALID_ARGUMENT
