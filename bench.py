@@ -3,7 +3,9 @@
 (BASELINE.json config 5: 2309 baked copies of rounded_cube, 4096x4096 film, PathIntegrator(5, 1.0), env-map light).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+  bench.py --gpus N ...) or plainly -- then bench.py starts its N ranks itself as a child process (fountain_amd/launch.py) and relays
+  rank 0's line.  A launcher whose WORLD_SIZE differs from --gpus is an error (exit code 2).
 
 A STEP is one pass of the hot path over one batch of camera samples: 16 N samples per pixel of the 4096x4096 film (--spp-per-gpu 16),
 with the film's 65,536 tiles interleaved over the N ranks -- so every GPU traces the same 268 M paths per step whatever N is
@@ -34,28 +36,54 @@ def main():
     ap.add_argument("--spp-per-gpu", type=int, default=int(os.environ.get("FTN_BENCH_SPP_PER_GPU", "16")), help="samples per pixel one GPU renders per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=int(os.environ.get("FTN_BENCH_CPU_TILES", "96")))
+    ap.add_argument("--dist-backend", default=os.environ.get("FTN_BENCH_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI, one GPU per rank (the measured configuration); gloo = rehearsal of the N-rank path (see --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank renders on GPU 0, films merged over gloo on the host")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, form the process group, print the result line's n_gpus -- no rendering (CPU test of the launcher)")
     args = ap.parse_args()
+
+    # ---- N ranks: either a launcher started us (WORLD_SIZE set), or we start the ranks ourselves -- as a child process, before
+    # torch / HIP are touched -- and relay rank 0's line
+    from fountain_amd.launch import spawn_ranks, world_from_env
+    env_world = world_from_env()
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__), json_only=True))
+    world, rank, local_rank = env_world if env_world is not None else (1, 0, 0)
+    if world != args.gpus:
+        print("error: --gpus %d but the launcher started WORLD_SIZE %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
-    from fountain_amd import Film, PathIntegrator, RandomSampler, SamplerIntegrator, default_backend, scenes, _abi as A
-    from fountain_amd.distributed import merge_film, tile_shard
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1"      # the latter: rehearse the collective path on one GPU
+    if args.share_gpu:
+        local_rank = 0
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        if args.dist_backend == "nccl" and not args.launch_check:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.launch_check:
+        t = torch.tensor([1.0, float(rank)])
+        if use_dist:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": int(t[0]), "rank_sum": int(t[1]), "world_size_env": world}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    from fountain_amd import Film, PathIntegrator, RandomSampler, SamplerIntegrator, default_backend, scenes, _abi as A
+    from fountain_amd.distributed import merge_film, tile_shard
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     gpu = default_backend()
+    host_merge = use_dist and args.dist_backend == "gloo"      # rehearsal: the reduce runs over gloo on a host copy of the film
 
     # ---- scene (host assembly + BVH::build + upload; not timed: SURVEY 8(d))
     t0 = time.time()
@@ -91,8 +119,16 @@ def main():
     dev_film.zero_()
     for i in range(args.warmup):
         step(i)
+    def merge():
+        if host_merge:
+            h = dev_film.cpu()
+            merge_film(h)
+            dev_film.copy_(h)
+        else:
+            merge_film(dev_film)              # the single end-of-frame reduce (RCCL over xGMI)
+
     if use_dist:
-        merge_film(dev_film)                  # untimed: the first large reduce also sets up RCCL's channels / buffers
+        merge()                               # untimed: the first large reduce also sets up RCCL's channels / buffers
     dev_film.zero_()
     barrier()
     t0 = time.perf_counter()
@@ -108,11 +144,11 @@ def main():
         trace_launches += st["trace_launches"]
         kernel_ms += st["kernel_ms"]
         cam_samples += st["camera_samples"]
-    merge_film(dev_film)                      # the single end-of-frame reduce (RCCL over xGMI)
+    merge()
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed, float(rays), float(cam_samples)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(rays), float(cam_samples)], dtype=torch.float64, device="cpu" if host_merge else dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -2,8 +2,8 @@
 (src/bin/render.rs:16-104) over the MI355X library -- parse the scene file, PathIntegrator::new(5, 1.0), render, write
 Film::into_spectrum_buffer as an OpenEXR file.
 
---threads of the reference has no meaning here; --gpu picks the HIP device.  Started under `python -m torch.distributed.run
---nproc-per-node N …` every rank renders the film tiles r, r+N, … on GPU LOCAL_RANK and the films are merged with the frame's single
+--threads of the reference has no meaning here; --gpu picks the HIP device.  With `--gpus N` (the program starts its N ranks itself,
+fountain_amd/launch.py) or started under `python -m torch.distributed.run --nproc-per-node N …` every rank renders the film tiles r, r+N, … on GPU LOCAL_RANK and the films are merged with the frame's single
 reduce (RCCL when every rank has its own GPU, gloo with --dist-backend gloo); rank 0 writes the image.  --exact-stream renders with the reference's own
 per-tile RandomSampler stream (one lane per 16x16 tile: for validation, slow); the default re-seeds per (pixel, sample) so that
 samples run in parallel (samplers).
@@ -26,9 +26,18 @@ def main(argv=None):
     ap.add_argument("--max-depth", type=int, default=5)          # render.rs:79 hard-codes PathIntegrator::new(5, 1.0)
     ap.add_argument("--rr-threshold", type=float, default=1.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--gpus", type=int, default=None, help="render on N GPUs of this node: film tiles r, r+N, ... per rank, one reduce at the end")
     opts = ap.parse_args(argv)
     import os
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    from .launch import spawn_ranks, world_from_env
+    env_world = world_from_env()
+    if env_world is None and opts.gpus is not None and opts.gpus > 1:
+        # started plainly: start the N ranks as a child process (before anything here has touched HIP) and hand back its exit code
+        return spawn_ranks(opts.gpus, sys.argv[1:] if argv is None else list(argv), module="fountain_amd.render")
+    world, rank = (env_world[0], env_world[1]) if env_world is not None else (1, 0)
+    if opts.gpus is not None and opts.gpus != world:
+        print("error: --gpus %d but the launcher started WORLD_SIZE %d ranks" % (opts.gpus, world), file=sys.stderr)
+        return 2
     if world > 1:
         opts.gpu = int(os.environ.get("LOCAL_RANK", "0")) if opts.dist_backend == "nccl" else opts.gpu
 

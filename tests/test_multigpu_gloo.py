@@ -75,3 +75,49 @@ def test_render_cli_under_torchrun(tmp_path):
     be = default_backend()
     a, b = read_exr(one, be), read_exr(two, be)
     assert a.shape == (64, 64, 3) and np.allclose(a, b, rtol=2e-6, atol=1e-7) and (a != b).mean() < 0.01 and a.mean() > 0.05
+
+
+def _run(cmd, env=None, timeout=300):
+    return subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no launcher environment) must start two ranks itself and report n_gpus = 2.
+    --launch-check stops after the process group has formed (no GPU here); the same code path carries the real run."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=dict(env, OMP_NUM_THREADS="1"),
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # stdout carries the result line alone
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_env"] == 2 and out["rank_sum"] == 1
+
+
+def test_bench_refuses_a_launcher_with_another_world_size():
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=dict(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and "WORLD_SIZE 3" in r.stderr
+
+
+def test_bench_rank_failure_is_an_error():
+    """a rank that dies makes the whole job exit non-zero (here: every rank fails at argument parsing)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from fountain_amd.launch import spawn_ranks; "
+                        "sys.exit(spawn_ranks(2, ['--no-such-flag'], script=%r))" % (ROOT, os.path.join(ROOT, "bench.py"))],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_this_box(tmp_path):
+    """the whole of `bench.py --gpus 2`, started plainly: two ranks (sharing this box's one GPU, films merged over gloo) render their
+    tile shards of a small scene; the line reports n_gpus 2 and twice the per-GPU camera samples"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--copies", "8", "--res", "256", "--spp-per-gpu", "2", "--steps", "2",
+                        "--warmup", "1", "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"], env=dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["camera_samples_per_step"] == 256 * 256 * 4 and out["value"] > 0
