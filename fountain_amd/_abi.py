@@ -132,7 +132,8 @@ class ftn_stats(C.Structure):
     _fields_ = [("rays_closest", c_u64), ("rays_any", c_u64), ("nodes_visited", c_u64), ("prims_tested", c_u64),
                 ("camera_samples", c_u64), ("spill_samples", c_u64), ("kernel_ms", C.c_double),
                 ("trace_ms", C.c_double), ("trace_launches", c_u64), ("nodes_visited_any", c_u64),
-                ("prims_tested_any", c_u64), ("mis_rays_any_hit", c_u64)]
+                ("prims_tested_any", c_u64), ("mis_rays_any_hit", c_u64), ("quad_records", c_u64), ("quad_records_any", c_u64),
+                ("any_ms", C.c_double), ("any_launches", c_u64), ("shade_ms", C.c_double), ("shade_launches", c_u64), ("sort_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -143,7 +144,7 @@ SIZES = {
     "ftn_transform": 128, "ftn_pixel": 16, "ftn_bvh_node": 32, "ftn_prim": 16, "ftn_mesh": 16,
     "ftn_sphere": 288, "ftn_material": 48, "ftn_light": 160, "ftn_envmap": 16, "ftn_camera_desc": 296,
     "ftn_film_desc": 32, "ftn_sampler_desc": 24, "ftn_integrator_desc": 16, "ftn_tile_range": 16,
-    "ftn_render_options": 16, "ftn_stats": 96, "ftn_texture": 48, "ftn_image": 24, "ftn_material_textures": 32,
+    "ftn_render_options": 16, "ftn_stats": 152, "ftn_texture": 48, "ftn_image": 24, "ftn_material_textures": 32,
 }
 
 # Every function the header declares (name -> None); used by the symbol-export test.
@@ -154,7 +155,7 @@ DECLARED_FUNCTIONS = [
     "ftn_transform_swaps_handedness", "ftn_transform_points", "ftn_transform_normals",
     "ftn_sphere_init", "ftn_camera_perspective", "ftn_film_init",
     "ftn_film_sample_bounds", "ftn_film_tile_count", "ftn_film_resolve", "ftn_scene_create",
-    "ftn_scene_destroy", "ftn_bvh_build", "ftn_scene_info", "ftn_scene_get_nodes", "ftn_scene_get_lights",
+    "ftn_scene_destroy", "ftn_bvh_build", "ftn_bvh_quads", "ftn_scene_info", "ftn_scene_get_nodes", "ftn_scene_get_lights",
     "ftn_intersect", "ftn_intersect_test", "ftn_intersect_full", "ftn_render", "ftn_render_device",
     "ftn_last_error", "ftn_device_count", "ftn_version", "ftn_test_math",
     "ftn_pbrt_load", "ftn_pbrt_destroy", "ftn_pbrt_scene", "ftn_pbrt_camera", "ftn_pbrt_film",

@@ -710,29 +710,31 @@ class Scene:
         return kind[:n], prim[:n]
 
     # Scene::intersect / intersect_test for a batch of rays: rays [n,8] = o, d, t_max, time
-    def intersect(self, rays, n_threads=8):
+    # stats=True asks for node / primitive tallies: the HIP library then runs the counting build of the REFERENCE-order walk (tallies
+    # equal the oracle's); stats=False runs the production kernels (four-box records, ftn_trace4.hip) and returns None for the tallies
+    def intersect(self, rays, n_threads=8, stats=True):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         n = rays.shape[0]
         t = np.empty(n, np.float32)
         prim = np.empty(n, np.int32)
         bary = np.zeros((n, 3), np.float32)
         st = A.ftn_stats()
-        args = [self.handle, _fptr(rays), C.c_size_t(n), _fptr(t), prim.ctypes.data_as(C.c_void_p), _fptr(bary), C.byref(st)]
+        args = [self.handle, _fptr(rays), C.c_size_t(n), _fptr(t), prim.ctypes.data_as(C.c_void_p), _fptr(bary), C.byref(st) if stats else None]
         if self.be.is_oracle:
             args.append(C.c_int(n_threads))
         self.be.call("intersect", *args)
-        return t, prim, bary, st.as_dict()
+        return t, prim, bary, (st.as_dict() if stats else None)
 
-    def intersect_test(self, rays, n_threads=8):
+    def intersect_test(self, rays, n_threads=8, stats=True):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         n = rays.shape[0]
         occ = np.empty(n, np.uint8)
         st = A.ftn_stats()
-        args = [self.handle, _fptr(rays), C.c_size_t(n), occ.ctypes.data_as(C.c_void_p), C.byref(st)]
+        args = [self.handle, _fptr(rays), C.c_size_t(n), occ.ctypes.data_as(C.c_void_p), C.byref(st) if stats else None]
         if self.be.is_oracle:
             args.append(C.c_int(n_threads))
         self.be.call("intersect_test", *args)
-        return occ.astype(bool), st.as_dict()
+        return occ.astype(bool), (st.as_dict() if stats else None)
 
     def intersect_full(self, rays, n_threads=8):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

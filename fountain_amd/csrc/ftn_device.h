@@ -87,6 +87,11 @@ struct DScene {
      * random place of a large scene).  8 float4 per primitive: {p0, flags} {p1, material} {p2, light} {n0, uv0.x} {n1, uv0.y}
      * {n2, uv1.x} {uv1.y, uv2.x, uv2.y, shape index} {unused}.  The traversal kernels keep reading the dense `geom`. */
     const float4* srec;
+    /* third view of the same BVH, what the production traversal kernels (ftn_trace4.hip) walk: one 128-byte record per two levels of
+     * the tree = the node records of an interior node's four grandchildren side by side (built by build_quads, ftn_host.cpp; NULL: not
+     * built).  quad_stack_bound: upper bound of the entries a walk can have pending. */
+    const float4* quad;
+    uint32_t n_quads, quad_stack_bound;
 };
 
 struct DCamera {

@@ -20,6 +20,7 @@
 #include <vector>
 #include <thread>
 #include <atomic>
+#include <limits>
 #include <functional>
 #include <cstdlib>
 
@@ -28,7 +29,7 @@ using namespace ftn;
 static_assert(sizeof(ftn_transform) == 128 && sizeof(ftn_pixel) == 16 && sizeof(ftn_bvh_node) == 32 && sizeof(ftn_prim) == 16, "ABI");
 static_assert(sizeof(ftn_mesh) == 16 && sizeof(ftn_sphere) == 288 && sizeof(ftn_material) == 48 && sizeof(ftn_light) == 160, "ABI");
 static_assert(sizeof(ftn_envmap) == 16 && sizeof(ftn_camera_desc) == 296 && sizeof(ftn_film_desc) == 32 && sizeof(ftn_sampler_desc) == 24, "ABI");
-static_assert(sizeof(ftn_integrator_desc) == 16 && sizeof(ftn_tile_range) == 16 && sizeof(ftn_render_options) == 16 && sizeof(ftn_stats) == 96, "ABI");
+static_assert(sizeof(ftn_integrator_desc) == 16 && sizeof(ftn_tile_range) == 16 && sizeof(ftn_render_options) == 16 && sizeof(ftn_stats) == 152, "ABI");
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -345,6 +346,78 @@ struct ParallelBvh {
     }
 };
 
+/* ------------------------------------------------------------------ four-box records (DScene::quad): the SAME tree, two levels per record
+ * One 128-byte record (= one cache line) per interior node R reached on even collapsed levels: the node records of R's grandchildren
+ * side by side, slots [A0, A1, B0, B1] with A = R's first child (bvh.rs: the next node) and B = its second child.  A child that is a
+ * leaf takes its pair's first slot itself (the second one is empty).  The traversal kernels (ftn_trace4.hip) test the four boxes of a
+ * record in one step and never test A's and B's own boxes:
+ *   - Bounds3f::intersect_test (bounds.rs:214-233) is monotone in the box -- every operation in it is a correctly rounded, monotone f32
+ *     operation and a NaN (0 * inf) only ever removes a constraint -- so a ray that enters a child's box enters its parent's box, for the
+ *     same or any larger t_max: skipping the parent's test changes nothing the reference would have visited;
+ *   - the reference's visiting order (near child first by dir_is_neg[split_axis], bvh.rs:187-196) of the four grandchildren follows from
+ *     the three split axes of R, A and B, which the record carries.
+ * Slot layout = the 32-byte node record of ftn_device.h: {min.x, max.x, min.y, max.y} {min.z, max.z, bits(link), bits(meta)};
+ * link = the traversal stack's entry for the child: byte offset of an interior child's own record, or first primitive | bit 31 for a
+ * leaf (its primitives run to the one flagged GF_LEAF_END in `geom`).  Slot 0's meta carries the three one-hot split axes that order
+ * the visit, one per byte: byte 0 A's (orders slots 0 / 1), byte 1 R's (orders the pairs), byte 2 B's (orders slots 2 / 3) -- tested
+ * against the ray's dir_is_neg bits repeated in the same bytes.  An empty slot (bit 25 of its meta, for tools) holds the box
+ * x = y = [0, 0], z = [+inf, +inf], which no ray with a finite non-zero 1/d enters: the kernels need no test for it.
+ * Returns the records in DFS order (slot order) and an upper bound of the traversal stack (entries pending at any time). */
+struct QuadBvh { std::vector<float> rec; /* 32 floats per record */ uint32_t n_records = 0, stack_bound = 0; bool ok = false; };
+static void build_quads(const std::vector<ftn_bvh_node>& nodes, QuadBvh* out) {
+    out->rec.clear(); out->n_records = 0; out->stack_bound = 0; out->ok = false;
+    if (nodes.empty() || nodes[0].is_leaf) { out->ok = true; return; }          /* no interior node: the kernels test the root's leaf directly */
+    /* pass 1: which interior nodes own a record, in DFS slot order (explicit stack: the tree can be 64 deep, the record tree 32) */
+    std::vector<uint32_t> owner_id(nodes.size(), 0xffffffffu), owners;
+    {
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty()) {
+            const uint32_t r = todo.back(); todo.pop_back();
+            owner_id[r] = (uint32_t)owners.size(); owners.push_back(r);
+            uint32_t gc[4]; int ng = 0;
+            const uint32_t ch[2] = {r + 1u, nodes[r].idx};
+            for (int k = 0; k < 2; k++) if (!nodes[ch[k]].is_leaf) { gc[ng++] = ch[k] + 1u; gc[ng++] = nodes[ch[k]].idx; }
+            for (int k = ng - 1; k >= 0; k--) if (!nodes[gc[k]].is_leaf) todo.push_back(gc[k]);      /* reversed: slot 0's subtree is numbered first */
+        }
+    }
+    if (owners.size() >= (1u << 24)) return;                                   /* links are 31-bit byte offsets: 2^24 records of 128 bytes */
+    out->n_records = (uint32_t)owners.size();
+    out->rec.assign((size_t)32 * owners.size(), 0.0f);
+    std::vector<uint32_t> bound(owners.size(), 0);
+    const float kInf = std::numeric_limits<float>::infinity();
+    auto put = [&](float* slot, const ftn_bvh_node* c, uint32_t c_index, uint32_t axis_bits) {
+        uint32_t link = 0, meta = axis_bits;
+        if (!c) { slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f; slot[3] = 0.0f; slot[4] = kInf; slot[5] = kInf; link = 0xffffffffu; meta |= 1u << 25; }      /* empty: fails every slab test */
+        else {
+            slot[0] = c->bmin[0]; slot[1] = c->bmax[0]; slot[2] = c->bmin[1]; slot[3] = c->bmax[1]; slot[4] = c->bmin[2]; slot[5] = c->bmax[2];
+            if (c->is_leaf) { link = c->idx | 0x80000000u; meta |= 1u << 24; }
+            else link = owner_id[c_index] * 128u;
+        }
+        slot[6] = ftn_det::u2f(link); slot[7] = ftn_det::u2f(meta);
+    };
+    for (size_t q = owners.size(); q-- > 0;) {                                  /* children have larger ids: their bounds are known */
+        const uint32_t r = owners[q];
+        const uint32_t ch[2] = {r + 1u, nodes[r].idx};
+        float* R = &out->rec[(size_t)32 * q];
+        uint32_t valid = 0, deepest = 0;
+        for (int k = 0; k < 2; k++) {
+            const ftn_bvh_node& c = nodes[ch[k]];
+            /* slot 0's meta: one-hot axes of A (byte 0), R (byte 1), B (byte 2); a leaf child has no axis (its pair has one member) */
+            const uint32_t axes = k == 0 ? ((c.is_leaf ? 0u : (1u << c.axis)) | ((1u << nodes[r].axis) << 8) | ((nodes[ch[1]].is_leaf ? 0u : (1u << nodes[ch[1]].axis)) << 16)) : 0u;
+            if (c.is_leaf) { put(R + 16 * k, &c, ch[k], axes); put(R + 16 * k + 8, nullptr, 0, 0u); valid += 1; }
+            else {
+                const uint32_t g0 = ch[k] + 1u, g1 = c.idx;
+                put(R + 16 * k, &nodes[g0], g0, axes); put(R + 16 * k + 8, &nodes[g1], g1, 0u); valid += 2;
+                if (!nodes[g0].is_leaf) deepest = std::max(deepest, bound[owner_id[g0]]);
+                if (!nodes[g1].is_leaf) deepest = std::max(deepest, bound[owner_id[g1]]);
+            }
+        }
+        bound[q] = (valid - 1u) + deepest;
+    }
+    out->stack_bound = bound[0];
+    out->ok = true;
+}
+
 struct HostScene {
     std::vector<ftn_bvh_node> nodes; std::vector<uint32_t> order; uint32_t max_depth = 0; Aabb world;
     std::vector<int32_t> light_kind, light_prim;
@@ -530,7 +603,7 @@ struct ftn_scene {
     int device = 0;
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
-    DevBuf<float4> nodes, geom, fat, srec; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
+    DevBuf<float4> nodes, geom, fat, srec, quad; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
     DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
@@ -539,7 +612,7 @@ struct ftn_scene {
     WavefrontState* wf = nullptr;
     std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
-        nodes.release(); geom.release(); fat.release(); srec.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
+        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
         for (auto& b : misc4) b.release();
         textures.release(); mtex.release(); images.release(); texels.release();
@@ -611,6 +684,18 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     /* two-box record links are 31-bit byte offsets: beyond 2^25 interior nodes the any-hit kernel falls back to the plain node walk */
     if (n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
     if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
+    /* four-box records (DScene::quad): what the production traversal kernels walk.  FTN_QUAD=0: not built (the two-record kernels run) */
+    uint32_t n_quads = 0, quad_bound = 0;
+    {
+        const char* knob = getenv("FTN_QUAD");
+        if (!knob || atoi(knob) != 0) {
+            QuadBvh qb; build_quads(hs.nodes, &qb);
+            if (qb.ok && qb.n_records) {
+                if ((rc = sc->quad.upload(reinterpret_cast<const float4*>(qb.rec.data()), (size_t)8 * qb.n_records))) return rc;
+                n_quads = qb.n_records; quad_bound = qb.stack_bound;
+            }
+        }
+    }
     /* shading records (DScene::srec): one 128-byte line per primitive with everything make_interaction reads.  FTN_SREC=0: not built */
     {
         const char* knob = getenv("FTN_SREC");
@@ -736,6 +821,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
     D.srec = sc->srec.p;
+    D.quad = sc->quad.p; D.n_quads = n_quads; D.quad_stack_bound = quad_bound;
     D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
     if (lights.size() == 1 && lights[0].kind == LK_INFINITE) { D.env_only = 1; D.env0 = lights[0]; }
@@ -778,7 +864,11 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
 static int set_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(FTN_ERR_NO_DEVICE, "no HIP device available: the fountain HIP path needs an AMD GPU (there is no CPU fallback)");
-    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    if (device >= 0) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { (void)hipGetLastError();      /* do not leave the error behind for the next call's hipGetLastError() */
+                               return fail(FTN_ERR_NO_DEVICE, std::string("hipSetDevice(device): ") + hipGetErrorString(e)); }
+    }
     return FTN_OK;
 }
 
@@ -794,6 +884,18 @@ int ftn_bvh_build(const ftn_scene_desc* d, ftn_bvh_node* nodes_out, uint32_t* or
     if (order_out) memcpy(order_out, hs.order.data(), hs.order.size() * sizeof(uint32_t));
     if (n_nodes_out) *n_nodes_out = (uint32_t)hs.nodes.size();
     if (max_depth_out) *max_depth_out = hs.max_depth;
+    return FTN_OK;
+}
+
+int ftn_bvh_quads(const ftn_bvh_node* nodes, uint32_t n_nodes, float* records_out, uint32_t* n_records_out, uint32_t* stack_bound_out) {
+    if (!nodes && n_nodes) return fail(FTN_ERR_INVALID_ARGUMENT, "null nodes");
+    std::vector<ftn_bvh_node> v(nodes, nodes + n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) if (!v[i].is_leaf && (v[i].idx <= i + 1 || v[i].idx >= n_nodes || v[i].axis > 2)) return fail(FTN_ERR_INVALID_ARGUMENT, "not a flattened BVH (bvh.rs:133-158)");
+    QuadBvh qb; build_quads(v, &qb);
+    if (!qb.ok) return fail(FTN_ERR_UNSUPPORTED, "more than 2^24 four-box records");
+    if (records_out) memcpy(records_out, qb.rec.data(), qb.rec.size() * sizeof(float));
+    if (n_records_out) *n_records_out = qb.n_records;
+    if (stack_bound_out) *stack_bound_out = qb.stack_bound;
     return FTN_OK;
 }
 
@@ -834,6 +936,7 @@ static void stats_out(const DevStats& ds, ftn_stats* st, double ms) {
     st->rays_closest = ds.rays_closest; st->rays_any = ds.rays_any; st->nodes_visited = ds.nodes_visited; st->prims_tested = ds.prims_tested;
     st->camera_samples = ds.camera_samples; st->spill_samples = ds.spill_samples; st->kernel_ms = ms;
     st->nodes_visited_any = ds.nodes_any; st->prims_tested_any = ds.prims_any;
+    st->quad_records = ds.quad_records; st->quad_records_any = ds.quad_records_any;
 }
 static int trace_batch(const ftn_scene* cs, const float* rays, size_t n, int mode, float* t_hit, int32_t* prim, float* bary, uint8_t* occ, float* out24, ftn_stats* st) {
     ftn_scene* s = const_cast<ftn_scene*>(cs);
@@ -964,7 +1067,10 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     s->spill_acc_dirty = ds.bc_writes != 0;
     ds.rays_closest += wt.mis_any_rays; ds.rays_any -= wt.mis_any_rays;       /* they are Scene::intersect calls in the reference's accounting */
     stats_out(ds, st, ms);
-    if (st) { st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; st->mis_rays_any_hit = wt.mis_any_rays; }
+    if (st) {
+        st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; st->mis_rays_any_hit = wt.mis_any_rays;
+        st->any_ms = wt.any_ms; st->any_launches = wt.any_launches; st->shade_ms = wt.shade_ms; st->shade_launches = wt.shade_launches; st->sort_ms = wt.sort_ms;
+    }
     if (ds.error == FTN_ERR_NAN_RADIANCE) return fail(FTN_ERR_NAN_RADIANCE, "NaN radiance value (integrator/mod.rs:285-287)");
     if (ds.error) return fail(ds.error, "unsupported material / integrator combination (e.g. specular glass: material/glass.rs:66)");
     return FTN_OK;
@@ -1016,6 +1122,7 @@ int ftn_film_resolve_device(const void* device_pixels, size_t n, void* device_rg
 int ftn_render(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn_film_desc* film, const ftn_sampler_desc* sd, const ftn_integrator_desc* id,
                const ftn_tile_range* tr, const ftn_render_options* opt, ftn_pixel* out_pixels, ftn_stats* st) {
     if (!cs || !film || !out_pixels) return fail(FTN_ERR_INVALID_ARGUMENT, "null argument");
+    if (opt && opt->device >= 0 && cs->device >= 0 && opt->device != cs->device) return fail(FTN_ERR_INVALID_ARGUMENT, "ftn_render_options.device differs from the device the scene was created on");
     int rc = set_device(opt && opt->device >= 0 ? opt->device : cs->device); if (rc) return rc;
     const size_t npix = (size_t)std::max(0, film->crop[2] - film->crop[0]) * (size_t)std::max(0, film->crop[3] - film->crop[1]);
     DevBuf<ftn_pixel> dev;

@@ -14,6 +14,7 @@ struct DevStats {
     unsigned long long bc_writes;   /* samples added into the spill accumulators accB / accC (0: both are still all zero) */
     int error;          /* 0 or an ftn_status (NaN radiance, unsupported material) */
     int _pad;
+    unsigned long long quad_records, quad_records_any;   /* four-box records fetched by the counting builds of k_wf_trace4 / k_wf_trace4_any */
 };
 
 struct DTile { int x0, y0, x1, y1; unsigned long long tile_id; uint32_t valid_off, _pad; };   /* sample-space tile, its sampler seed, exclusive prefix sum of pixel counts */

@@ -10,6 +10,7 @@
 namespace ftn {
 struct WavefrontState;
 struct WavefrontTimes { double trace_ms; unsigned long long trace_launches;
+                        double any_ms; unsigned long long any_launches; double shade_ms; unsigned long long shade_launches; double sort_ms;   /* the other kernel groups of a bounce (HIP events on their stream) */
                         unsigned long long mis_any_rays; /* Scene::intersect calls of estimate_direct answered by the any-hit kernel (infinite lights: only hit / miss matters) */ };
 int wavefront_render(WavefrontState** state, const RenderParams& P, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times,
                      bool count_production = false);

@@ -28,7 +28,7 @@
  * pipelines produce identical radiance.  Dominant kernel: k_wf_trace<false>; roofline = HBM (node + triangle fetches), in
  * practice the L2 -> L1 gather rate.
  */
-#include "ftn_wavefront.h"
+#include "ftn_wf_common.h"
 #include "ftn_texture.h"
 #include <string>
 #include <cstdlib>
@@ -37,87 +37,6 @@
 namespace ftn {
 
 /* pstate bits */
-/* the bounce count takes 16 bits: PathIntegrator::max_depth is a u16 in the reference (path.rs:14), and ftn_render_device refuses more */
-enum : uint32_t { PS_BOUNCE_MASK = 0xffffu, PS_SPECULAR = 1u << 16, PS_ALIVE = 1u << 17, PS_DIRECT = 1u << 18, PS_SHADOW = 1u << 19, PS_MIS = 1u << 20, PS_DELTA = 1u << 21, PS_MIS_ANY = 1u << 22 /* the MIS ray went through the any-hit kernel */ };
-#define WF_MIS_BIT 0x80000000u
-
-struct WfBuffers {
-    uint32_t n_paths;           /* n_slots * samples; path id = slot * samples + sample */
-    uint32_t n_slots;           /* tiles * 256 */
-    uint32_t samples;           /* S */
-    uint32_t first_sample;      /* 0-based index of this pass's first sample */
-    /* rays / hits: index r in [0, n_paths) = continuation ray of path r, [n_paths, 2 n_paths) = MIS ray of path r - n_paths */
-    float4 *ray;                /* 2 float4 per ray, adjacent (one 32-byte record = one line fetch when rays are read in sorted order): {o.xyz, -} {d.xyz, t_max} */
-    float4* hit;                /* t, b0, b1, b2 */
-    int* hit_prim;
-    float4 *sh;                 /* shadow rays, per path, same 32-byte record */
-    unsigned char* occluded;    /* per path */
-    float4 *beta;               /* beta.xyz, bits(pstate) */
-    float4 *rad;                /* L.xyz, bits(light index of the pending direct term) */
-    ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
-    float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
-    float2* p_film;             /* the camera sample's film position (for the in-order film add) */
-    uint32_t *q_active[2], *q_closest, *q_shadow;
-    uint32_t* q_sorted;         /* the active queue grouped by shading class (material-sorted shading) */
-    uint32_t* cls;              /* per-class path counts, one 128-byte line each (CTR(k)) */
-    uint32_t seg_cap;           /* capacity of one class segment of q_sorted */
-    uint32_t* counters;         /* one 128-byte line each (CTR(i) = 32*i): 0 active A, 1 active B, 2 closest, 3 shadow, 4 head closest, 5 head shadow */
-    uint32_t valid_per_sample;  /* camera samples per spp pass (sum of the tiles' pixel counts) */
-    uint32_t* drain_sig; uint32_t drain_seq, drain_at;   /* closest-hit trace: where (signal memory) and what to store once a wave finds the queue dry (NULL: nobody waits) */
-    uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
-};
-
-#define CTR(i) ((i) * 32)
-__device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
-/* wave-level queue append: one atomic per wave (ballot / popc compaction) */
-__device__ inline void wave_push(bool pred, uint32_t value, uint32_t* queue, uint32_t* counter) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0) return;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = value;
-}
-
-/* block-level queue append: ballot per wave, ONE global atomic per workgroup and queue (same-address atomics retire at
- * ~88 per microsecond on this part, so per-wave appends to one word were the bottleneck of generate/shade) */
-template <int NQ>
-__device__ inline void block_push(const bool (&pred)[NQ], const uint32_t (&value)[NQ], uint32_t* const (&queue)[NQ], uint32_t* const (&counter)[NQ]) {
-    __shared__ uint32_t s_cnt[NQ][4];
-    __shared__ uint32_t s_base[NQ];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    unsigned long long m[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) { m[q] = __ballot(pred[q]); if (lane == 0) s_cnt[q][wave] = (uint32_t)__popcll(m[q]); }
-    __syncthreads();
-    if (threadIdx.x < NQ) {
-        const uint32_t q = threadIdx.x;
-        const uint32_t tot = s_cnt[q][0] + s_cnt[q][1] + s_cnt[q][2] + s_cnt[q][3];
-        s_base[q] = tot ? atomicAdd(counter[q], tot) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        if (pred[q]) {
-            uint32_t off = s_base[q];
-            for (uint32_t w = 0; w < wave; w++) off += s_cnt[q][w];
-            if (queue[q]) queue[q][off + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull))] = value[q];
-        }
-    }
-    __syncthreads();   /* s_cnt / s_base are reused by the next round */
-}
-
-/* A queue entry is a path id; WF_MIS_BIT marks the path's MIS ray (record n_paths + id) instead of its continuation ray (closest-hit
- * queue) or its shadow ray (any-hit queue).  *slot: index of the ray's result (hit[] / hit_prim[] for closest hits, occluded[] for
- * any-hit: shadow results at [0, n_paths), MIS-ray results at [n_paths, 2 n_paths)). */
-template <bool ANY>
-__device__ inline void load_queued_ray(const WfBuffers& W, uint32_t rid, float4* a, float4* b, uint32_t* slot) {
-    const uint32_t pid = rid & ~WF_MIS_BIT;
-    if (ANY && !(rid & WF_MIS_BIT)) { *a = W.sh[2 * (size_t)pid]; *b = W.sh[2 * (size_t)pid + 1]; *slot = pid; }
-    else { const uint32_t r = (rid & WF_MIS_BIT) ? pid + W.n_paths : pid; *a = W.ray[2 * (size_t)r]; *b = W.ray[2 * (size_t)r + 1]; *slot = r; }
-}
-
 /* ------------------------------------------------------------------ generate (no atomics: queue slots are known in closed form) */
 __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;          /* path id = slot * samples + s: the samples of a pixel are neighbours */
@@ -146,62 +65,6 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         W.q_active[0][qi] = i;
         W.q_closest[qi] = i;
     }
-}
-
-/* one primitive of a leaf against the ray: Triangle::intersect's hit test (triangle.rs:183-268) with the per-ray permutation
- * (kz) and shear (sx, sy, sz) hoisted, or Sphere::intersect */
-template <bool SPHERES>
-__device__ inline bool prim_hit(const DScene& S, uint32_t prim, float4 g0, float4 g1, float4 g2, V3 o, V3 dorig, float t_max, int kz, float sx, float sy, float sz,
-                                float* t_out, float* b0o, float* b1o, float* b2o) {
-    const uint32_t fl = __float_as_uint(g0.w);
-    float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh = false;
-    if (SPHERES && (fl & GF_KIND_SPHERE)) {
-        DRay r; r.o = o; r.d = dorig; r.t_max = t_max; r.time = 0.0f;
-        hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
-    } else {
-        /* Triangle::intersect hit test (triangle.rs:183-268) with the per-ray constants hoisted */
-        /* permute_point(p - o, kx, ky, kz) with (kx, ky, kz) = (kz+1, kz+2, kz) mod 3, as selects on registers */
-        const bool k0 = kz == 0, k1 = kz == 1;
-#define FTN_PERM(v) V3(k0 ? (v).y : (k1 ? (v).z : (v).x), k0 ? (v).z : (k1 ? (v).x : (v).y), k0 ? (v).x : (k1 ? (v).y : (v).z))
-        const V3 op = FTN_PERM(o);
-        V3 p0t = FTN_PERM(g0), p1t = FTN_PERM(g1), p2t = FTN_PERM(g2);
-#undef FTN_PERM
-        p0t = V3(p0t.x - op.x, p0t.y - op.y, p0t.z - op.z);
-        p1t = V3(p1t.x - op.x, p1t.y - op.y, p1t.z - op.z);
-        p2t = V3(p2t.x - op.x, p2t.y - op.y, p2t.z - op.z);
-        p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
-        p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
-        p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
-        float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
-        float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
-        float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
-        if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
-            e0 = (float)((double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x);
-            e1 = (float)((double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x);
-            e2 = (float)((double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x);
-        }
-        const float det = e0 + e1 + e2;
-        if (!(sign_pos(e0) != sign_pos(e1) || sign_pos(e1) != sign_pos(e2)) && det != 0.0f) {
-            p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
-            const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-            if (!((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)))) {
-                const float inv_det = 1.0f / det;
-                b0 = e0 * inv_det; b1 = e1 * inv_det; b2 = e2 * inv_det; t = t_scaled * inv_det;
-                const float max_zt = fmax_(fmax_(fabsf(p0t.z), fabsf(p1t.z)), fabsf(p2t.z));
-                const float delta_z = gamma_n(3) * max_zt;
-                const float max_xt = fmax_(fmax_(fabsf(p0t.x), fabsf(p1t.x)), fabsf(p2t.x));
-                const float max_yt = fmax_(fmax_(fabsf(p0t.y), fabsf(p1t.y)), fabsf(p2t.y));
-                const float delta_x = gamma_n(5) * (max_xt + max_zt), delta_y = gamma_n(5) * (max_yt + max_zt);
-                const float delta_e = 2.0f * (gamma_n(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
-                const float max_e = fmax_(fmax_(fabsf(e0), fabsf(e1)), fabsf(e2));
-                const float delta_t = 3.0f * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
-                hh = !(t <= delta_t);
-                if (hh && (fl & GF_HAS_UVS) && tri_uv_degenerate_reject(S, (int)prim, V3(g0.x, g0.y, g0.z), V3(g1.x, g1.y, g1.z), V3(g2.x, g2.y, g2.z))) hh = false;
-            }
-        }
-    }
-    *t_out = t; *b0o = b0; *b1o = b1; *b2o = b2;
-    return hh;
 }
 
 /* ------------------------------------------------------------------ trace
@@ -342,7 +205,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             atomicAdd(&W.counters[CTR(8)], w_idle_lanes >> 6); atomicAdd(&W.counters[CTR(9)], w_leafwait_lanes >> 6);     /* in units of 64 lanes */
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) { if (ANY) atomicAdd(&stats->rays_any, (unsigned long long)count); else atomicAdd(&stats->rays_closest, (unsigned long long)count); }   /* (NULL: the rays were counted by the kernel that handed them over) */
 }
 
 /* ------------------------------------------------------------------ any-hit traversal over two-box records
@@ -747,7 +610,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
 __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {                                                                         /* new pass: generate fills both queues densely */
-        for (int i = 0; i < 32; i++) W.counters[CTR(i)] = 0;
+        for (int i = 0; i < 64; i++) W.counters[CTR(i)] = 0;
 #ifdef FTN_DRAIN_PROBE
         for (int k = 0; k < 32; k++) W.counters[CTR(13) + k] = 0;
 #endif
@@ -756,6 +619,7 @@ __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     } else if (mode == 1) {                                                                  /* before shade */
         W.counters[CTR(2)] = 0; W.counters[CTR(3)] = 0; W.counters[CTR(in_q == 0 ? 1 : 0)] = 0; W.counters[CTR(11)] = 0;
         for (int i = 16; i < 32; i++) W.counters[CTR(i)] = 0;                                /* the per-XCD queue heads of the two trace kernels */
+        for (int i = 32; i < 56; i++) W.counters[CTR(i)] = 0;                                /* exception queues of the four-box kernels: counts and heads */
     } else if (mode == 2) {                                                                  /* before classify */
         for (int i = 0; i < WF_NCLASS; i++) W.cls[CTR(i)] = 0;
     }
@@ -867,13 +731,16 @@ __global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, cons
 struct WavefrontState {
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     size_t cap_paths = 0;
-    void* mem[32]; int n_mem = 0;
+    void* mem[40]; int n_mem = 0;
     WfBuffers W;
     hipEvent_t ev[64]; int n_ev = 0;
     hipStream_t side = nullptr; hipEvent_t ev_ready = nullptr, ev_side = nullptr;     /* the any-hit launches run beside the closest-hit ones */
     uint32_t* drain_sig = nullptr; uint32_t drain_seq = 0;                              /* signal memory for hipStreamWaitValue32 (NULL: not supported) */
     uint32_t* host_counters = nullptr;    /* pinned */
     int n_cu = 256;
+    /* four-box traversal (ftn_trace4.hip): launch plan of the current call and the global spill areas behind the LDS stacks */
+    Trace4Plan t4; bool t4_on = false;
+    void* t4_spill_c = nullptr; void* t4_spill_a = nullptr; size_t t4_spill_c_bytes = 0, t4_spill_a_bytes = 0;
 };
 #define WF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_wf_err = std::string(#expr ": ") + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE; } } while (0)
 
@@ -887,6 +754,8 @@ void wavefront_destroy(WavefrontState* st) {
     if (st->ev_side) (void)hipEventDestroy(st->ev_side);
     if (st->side) (void)hipStreamDestroy(st->side);
     if (st->drain_sig) (void)hipFree(st->drain_sig);
+    if (st->t4_spill_c) (void)hipFree(st->t4_spill_c);
+    if (st->t4_spill_a) (void)hipFree(st->t4_spill_a);
     if (st->host_counters) (void)hipHostFree(st->host_counters);
     delete st;
 }
@@ -903,7 +772,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.counters, 32 * 32))) return rc;
+        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -941,14 +810,49 @@ static int sort_ray_queue(WavefrontState* st, const RenderParams& P, const WfBuf
 #ifdef FTN_DRAIN_PROBE
 static uint32_t g_probe_bounce = 0;
 #endif
-static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int n_cu, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
+/* Sizes the four-box kernels' launches for this call (LDS levels -> occupancy, persistent grid) and makes sure their spill areas exist.
+ * FTN_TRACE4=0 or a scene without four-box records: the two-record kernels run. */
+static int trace4_prepare(WavefrontState* st, const DScene& S) {
+    st->t4_on = S.quad != nullptr && knob("FTN_TRACE4", 1) != 0;
+    if (!st->t4_on) return FTN_OK;
+    st->t4 = trace4_plan(S, st->n_cu, knob("FTN_T4_ENTRIES", 0), knob("FTN_T4_ENTRIES_ANY", 0), knob("FTN_T4_WG", 0), knob("FTN_T4_WG_ANY", 0));
+    const size_t need_c = (size_t)st->t4.grid_closest * 256u * st->t4.spill_closest * sizeof(uint2), need_a = (size_t)st->t4.grid_any * 256u * st->t4.spill_any * sizeof(uint32_t);
+    if (need_c > st->t4_spill_c_bytes) { if (st->t4_spill_c) (void)hipFree(st->t4_spill_c); st->t4_spill_c = nullptr; st->t4_spill_c_bytes = 0; WF_TRY(hipMalloc(&st->t4_spill_c, need_c)); st->t4_spill_c_bytes = need_c; }
+    if (need_a > st->t4_spill_a_bytes) { if (st->t4_spill_a) (void)hipFree(st->t4_spill_a); st->t4_spill_a = nullptr; st->t4_spill_a_bytes = 0; WF_TRY(hipMalloc(&st->t4_spill_a, need_a)); st->t4_spill_a_bytes = need_a; }
+    return FTN_OK;
+}
+
+/* count: 0 = production kernels, 1 = counting build of the REFERENCE walk (node / primitive tallies equal the oracle's), 2 = counting
+ * build of the production kernels (what bench.py's byte model uses).  n_queue: upper bound of the queue's length (sizes the grid). */
+static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, unsigned grid, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
                          const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
+    if (st->t4_on && count != 1) {     /* four-box records */
+        const Trace4Plan& T = st->t4;
+        const unsigned g = std::min<unsigned>(any ? T.grid_any : T.grid_closest, std::max<unsigned>(1u, (max_rays + 255u) / 256u));
+        uint32_t chunk4 = knob("FTN_TRACE_CHUNK", 128);
+        while (chunk4 > 64u && (uint64_t)chunk4 * g * 4u * 4u > (uint64_t)max_rays) chunk4 >>= 1;
+        launch_trace4(any, count == 2, spheres, g, any ? T.lds_any : T.lds_closest, any ? T.entries_any : T.entries_closest, any ? st->t4_spill_a : st->t4_spill_c, stream, P.S, W,
+                      queue, count_ptr, head, P.stats, /* measured optima on the config-5 scene (profiles/r02_*): lanes re-armed once 24 (closest) / 32 (any-hit) are idle, leaf steps run
+                       * once 16 lanes hold a leaf, 2 / 4 record steps per control round */
+                      any ? knob("FTN_T4_ANY_REFILL", 32) : knob("FTN_T4_REFILL", 24), any ? knob("FTN_T4_ANY_LEAF_BATCH", 16) : knob("FTN_T4_LEAF_BATCH", 16), chunk4,
+                      any ? knob("FTN_T4_ANY_BURST", 4) : knob("FTN_T4_BURST", 2), knob("FTN_T4_ANY_POLICY", 1), any ? T.spill_any : T.spill_closest);
+        /* the rays it handed back (a zero direction component: ftn_trace4.hip, point 5) take the reference-order kernel.  The queue is
+         * nearly always empty and the persistent workgroups leave at once; its rays are already in the statistics (stats = NULL) */
+        const unsigned ge = std::min<unsigned>(grid, (unsigned)st->n_cu);
+        uint32_t* ecount = &W.counters[CTR(any ? 33 : 32)]; uint32_t* ehead = &W.counters[CTR(any ? 48 : 40)];
+        DevStats* none = nullptr;
+#define FTN_TRE(A, Sp) hipLaunchKernelGGL((k_wf_trace<A, false, Sp, 8>), dim3(ge), dim3(256), lds, stream, P.S, W, any ? W.q_exc_any : W.q_exc_closest, ecount, ehead, none, 24u, 2u, 64u, 8u)
+        if (any) { if (spheres) FTN_TRE(true, true); else FTN_TRE(true, false); } else { if (spheres) FTN_TRE(false, true); else FTN_TRE(false, false); }
+#undef FTN_TRE
+        return;
+    }
+    const bool count_b = count != 0;
     const uint32_t refill = knob("FTN_TRACE_REFILL", 24), leaf_batch = knob("FTN_TRACE_LEAF_BATCH", 2), chunk_knob = knob("FTN_TRACE_CHUNK", 128), node_burst = knob("FTN_TRACE_BURST", 8);
     /* per-wave chunk: large enough that queue-head atomics are rare, small enough that the tail spreads over all waves */
     uint32_t chunk = chunk_knob;
     const uint32_t waves = grid * 4u;
     while (chunk > 64u && (uint64_t)chunk * waves * 4u > (uint64_t)max_rays) chunk >>= 1;
-    if (any && !count && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
+    if (any && !count_b && knob("FTN_TRACE_ANY2", 1) && P.S.fat) {     /* any-hit rays: two boxes per step (k_wf_trace_any2) */
         const uint32_t refill2 = knob("FTN_ANY2_REFILL", 16), leaf_batch2 = knob("FTN_ANY2_LEAF_BATCH", leaf_batch);
         uint32_t policy2 = knob("FTN_ANY2_POLICY", 2);
 #ifdef FTN_DRAIN_PROBE
@@ -960,10 +864,10 @@ static void launch_trace(bool any, bool count, bool spheres, unsigned grid, int 
     }
     lds += knob("FTN_TRACE_LDS_PAD", 0);     /* experiment: lower the occupancy */
 #define FTN_TR(A, C, Sp, B) hipLaunchKernelGGL((k_wf_trace<A, C, Sp, B>), dim3(grid), dim3(256), lds, stream, P.S, W, queue, count_ptr, head, P.stats, refill, leaf_batch, chunk, node_burst)
-    const bool fixed = node_burst == 8 && !count && !knob("FTN_TRACE_NO_UNROLL", 0);      /* the default burst is compiled in (unrolled) */
+    const bool fixed = node_burst == 8 && !count_b && !knob("FTN_TRACE_NO_UNROLL", 0);      /* the default burst is compiled in (unrolled) */
     if (fixed) { if (any) { if (spheres) FTN_TR(true, false, true, 8); else FTN_TR(true, false, false, 8); } else { if (spheres) FTN_TR(false, false, true, 8); else FTN_TR(false, false, false, 8); } }
-    else if (any) { if (count) { if (spheres) FTN_TR(true, true, true, 0); else FTN_TR(true, true, false, 0); } else { if (spheres) FTN_TR(true, false, true, 0); else FTN_TR(true, false, false, 0); } }
-    else { if (count) { if (spheres) FTN_TR(false, true, true, 0); else FTN_TR(false, true, false, 0); } else { if (spheres) FTN_TR(false, false, true, 0); else FTN_TR(false, false, false, 0); } }
+    else if (any) { if (count_b) { if (spheres) FTN_TR(true, true, true, 0); else FTN_TR(true, true, false, 0); } else { if (spheres) FTN_TR(true, false, true, 0); else FTN_TR(true, false, false, 0); } }
+    else { if (count_b) { if (spheres) FTN_TR(false, true, true, 0); else FTN_TR(false, true, false, 0); } else { if (spheres) FTN_TR(false, false, true, 0); else FTN_TR(false, false, false, 0); } }
 #undef FTN_TR
 }
 
@@ -1032,25 +936,27 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
     knobs_begin();
     int rc = wf_state_init(state); if (rc) return rc;
     WavefrontState* st = *state;
+    if ((rc = trace4_prepare(st, S))) return rc;
     const uint32_t n = (uint32_t)n_rays;
     const bool any = mode == 1;
-    float4 *ray = nullptr, *hit = nullptr; int* hit_prim = nullptr; uint32_t *queue = nullptr, *scratch = nullptr, *counters = nullptr;
-    auto cleanup = [&]() { (void)hipFree(ray); (void)hipFree(hit); (void)hipFree(hit_prim); (void)hipFree(queue); (void)hipFree(scratch); (void)hipFree(counters); };
+    float4 *ray = nullptr, *hit = nullptr; int* hit_prim = nullptr; uint32_t *queue = nullptr, *scratch = nullptr, *counters = nullptr, *q_exc = nullptr;
+    auto cleanup = [&]() { (void)hipFree(ray); (void)hipFree(hit); (void)hipFree(hit_prim); (void)hipFree(queue); (void)hipFree(scratch); (void)hipFree(counters); (void)hipFree(q_exc); };
 #define WFB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_wf_err = std::string(#expr ": ") + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE; } } while (0)
     WFB_TRY(hipMalloc((void**)&ray, (size_t)n * 32)); WFB_TRY(hipMalloc((void**)&queue, (size_t)n * 4)); WFB_TRY(hipMalloc((void**)&scratch, (size_t)n * 12));
-    WFB_TRY(hipMalloc((void**)&counters, 32 * 32 * 4)); WFB_TRY(hipMemsetAsync(counters, 0, 32 * 32 * 4, stream));
+    WFB_TRY(hipMalloc((void**)&counters, 64 * 32 * 4)); WFB_TRY(hipMemsetAsync(counters, 0, 64 * 32 * 4, stream));
+    WFB_TRY(hipMalloc((void**)&q_exc, (size_t)n * 4));
     if (!any) { WFB_TRY(hipMalloc((void**)&hit, (size_t)n * 16)); WFB_TRY(hipMalloc((void**)&hit_prim, (size_t)n * 4)); }
     hipLaunchKernelGGL(k_batch_setup, dim3((n + 255) / 256), dim3(256), 0, stream, d_rays8, n, ray, queue);
     WFB_TRY(hipMemcpyAsync(&counters[CTR(any ? 3 : 2)], &n, 4, hipMemcpyHostToDevice, stream));
     WfBuffers W; memset(&W, 0, sizeof(W));
-    W.n_paths = n; W.ray = ray; W.sh = ray; W.hit = hit; W.hit_prim = hit_prim; W.occluded = occluded; W.counters = counters;
+    W.n_paths = n; W.ray = ray; W.sh = ray; W.hit = hit; W.hit_prim = hit_prim; W.occluded = occluded; W.counters = counters; W.q_exc_closest = q_exc; W.q_exc_any = q_exc;
     RenderParams P; memset(&P, 0, sizeof(P)); P.S = S; P.stats = stats;
     const uint32_t* q = queue;
     if (knob("FTN_WF_SORT", 1)) { rc = sort_ray_queue(st, P, W, any, queue, n, scratch, scratch + n, scratch + 2 * (size_t)n, 7, stream, &q); if (rc) { cleanup(); return rc; } }
     const size_t lds = (size_t)stack_entries * 256 * sizeof(uint32_t);
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned grid = std::min<unsigned>((unsigned)st->n_cu * per_cu, (n + 255) / 256);
-    launch_trace(any, count, S.n_spheres != 0, grid, st->n_cu, lds, stream, P, W, q, &counters[CTR(any ? 3 : 2)], &counters[CTR(any ? 24 : 16)], n);
+    launch_trace(st, any, count ? 1 : 0, S.n_spheres != 0, grid, lds, stream, P, W, q, &counters[CTR(any ? 3 : 2)], &counters[CTR(any ? 24 : 16)], n);
     if (!any) hipLaunchKernelGGL(k_batch_finish, dim3((n + 255) / 256), dim3(256), 0, stream, S, d_rays8, n, hit, hit_prim, t_hit, prim, bary, out24);
     WFB_TRY(hipStreamSynchronize(stream));
     WFB_TRY(hipGetLastError());
@@ -1084,6 +990,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
         rc = wf_reserve(st, (size_t)S * n_slots);
     }
     if (rc) { wf_free(st); return rc; }
+    if ((rc = trace4_prepare(st, P.S))) return rc;
+    const int count_mode = count ? (count_production ? 2 : 1) : 0;
     WfBuffers W = st->W;
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
@@ -1094,6 +1002,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
     const unsigned shade_grid_max = (unsigned)st->n_cu * 8u;
     double trace_ms = 0.0; unsigned long long trace_launches = 0, mis_any_rays = 0;
+    double group_ms[4] = {0.0, 0.0, 0.0, 0.0}; unsigned long long group_n[4] = {0, 0, 0, 0};     /* 0 closest-hit trace, 1 any-hit trace, 2 classify + shade, 3 queue sort */
     /* (rocprofv3's counter collection runs one dispatch at a time and never gets to the launch a stream-memory wait is waiting for:
      * with ROCPROF_COUNTER_COLLECTION set the gate is left out -- kernels are serialised under that tool anyway) */
     /* FTN_WF_OVERLAP: 0 = one stream, 1 = any-hit launches beside the closest-hit ones, 2 (default) = only for wavefronts of up to 32 Mi
@@ -1102,15 +1011,24 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const bool drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     int ev_used = 0;
-    struct Span { int a, b; };
+    struct Span { int a, b, kind; };
     std::vector<Span> spans;
+    static const char* const kGroup[4] = {"closest-hit trace", "any-hit trace", "classify + shade", "queue sort"};
     auto flush_events = [&]() -> int {
         if (spans.empty()) return FTN_OK;
-        WF_TRY(hipEventSynchronize(st->ev[spans.back().b]));
-        for (const Span& s : spans) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, st->ev[s.a], st->ev[s.b]); trace_ms += ms; if (knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] closest-hit launch: %.3f ms\n", ms); }
+        for (const Span& s : spans) WF_TRY(hipEventSynchronize(st->ev[s.b]));       /* (the any-hit launches may sit on the side stream) */
+        for (const Span& s : spans) {
+            float ms = 0.0f; (void)hipEventElapsedTime(&ms, st->ev[s.a], st->ev[s.b]);
+            group_ms[s.kind] += ms; group_n[s.kind]++;
+            if (s.kind == 0) trace_ms += ms;
+            if (knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] %s: %.3f ms\n", kGroup[s.kind], ms);
+        }
         spans.clear(); ev_used = 0;
         return FTN_OK;
     };
+    /* HIP events around a group of launches on the stream they are launched on */
+    auto span_begin = [&](hipStream_t sm) -> int { const int a = ev_used++; (void)hipEventRecord(st->ev[a], sm); return a; };
+    auto span_end = [&](int a, int kind, hipStream_t sm) { const int b = ev_used++; (void)hipEventRecord(st->ev[b], sm); spans.push_back(Span{a, b, kind}); };
     for (uint32_t s0 = 0; s0 < total_samples; s0 += S) {
         const uint32_t Sp = std::min(S, total_samples - s0);
         W.n_slots = n_slots; W.samples = Sp; W.n_paths = Sp * n_slots; W.first_sample = P.first_sample + s0; W.seg_cap = (uint32_t)st->cap_paths;
@@ -1124,7 +1042,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
         for (uint32_t it = 0; it < max_iter; it++) {
             bool polled = false;
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
-            if (ev_used + 2 > 64) { rc = flush_events(); if (rc) return rc; }
+            if (ev_used + 8 > 64) { rc = flush_events(); if (rc) return rc; }
             /* The two traces of a bounce are independent (own queues, own result arrays).  A persistent traversal kernel ends with a
              * long drain -- the last rays are sequential walks of several hundred nodes while most waves have already left (measured:
              * 0.3-0.8 ms from the first idle wave to the end of every launch) -- so the any-hit launch goes to a second stream and its
@@ -1145,20 +1063,24 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 W.drain_sig = st->drain_sig; W.drain_seq = ++st->drain_seq;
                 W.drain_at = 1;           /* the first wave (waiting for 10-75 % of the waves to be dry measured the same) */
             }
-            WF_TRY(hipEventRecord(st->ev[ev_used], stream));
-            launch_trace(false, count, spheres, tg, st->n_cu, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
-            WF_TRY(hipEventRecord(st->ev[ev_used + 1], stream));
+            { const int e = span_begin(stream);
+              launch_trace(st, false, count_mode, spheres, tg, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
+              span_end(e, 0, stream); }
             if (gated) WF_TRY(hipStreamWriteValue32(stream, st->drain_sig, W.drain_seq, 0));
-            spans.push_back(Span{ev_used, ev_used + 1}); ev_used += 2; trace_launches++;
+            trace_launches++;
             /* the side stream's waits are enqueued AFTER the launch they wait for: a tool that executes everything one command at a time
              * in submission order (rocprofv3 --pmc) then meets launch, release, wait -- not a wait nothing can release */
             if (beside) WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0));
             if (gated) WF_TRY(hipStreamWaitValue32(st->side, st->drain_sig, W.drain_seq, hipStreamWaitValueGte, 0xffffffffu));
             if (it > 0) {
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
-                launch_trace(true, count, spheres, sg, st->n_cu, lds, beside ? st->side : stream, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);
+                hipStream_t as = beside ? st->side : stream;
+                const int e = span_begin(as);
+                launch_trace(st, true, count_mode, spheres, sg, lds, as, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);
+                span_end(e, 1, as);
                 if (beside) WF_TRY(hipEventRecord(st->ev_side, st->side));
             }
+            const int e_shade = span_begin(stream);
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
                 hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
@@ -1187,6 +1109,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
 #undef FTN_SH
                 }
             }
+            span_end(e_shade, 2, stream);
             in_q ^= 1;
             if (sort_bits) {   /* order the two ray queues the next traces read (needs their lengths on the host: one small read-back) */
                 WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1199,9 +1122,11 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 const size_t n = st->cap_paths;                        /* scratch: q_sorted is free until the next classify */
                 uint32_t* const k_in = W.q_sorted + 4 * n, *const k_out = W.q_sorted + 6 * n;     /* [0,2n) sorted closest, [2n,4n) sorted any-hit, keys in / out */
                 q_cl = W.q_closest; q_sh = W.q_shadow;
+                const int e_sort = span_begin(stream);
                 if ((rc = sort_ray_queue(st, P, W, false, W.q_closest, st->host_counters[CTR(2)], W.q_sorted, k_in, k_out, sort_bits, stream, &q_cl))) return rc;
                 /* the any-hit queue stays in shading order: with the two-box kernel its sort (24 M entries per step) costs more than it returns */
                 if (knob("FTN_WF_SORT_ANY", 0) && (rc = sort_ray_queue(st, P, W, true, W.q_shadow, st->host_counters[CTR(3)], W.q_sorted + 2 * n, k_in, k_out, sort_bits, stream, &q_sh))) return rc;
+                span_end(e_sort, 3, stream);
             }
             if (it >= P.max_depth || polled) {   /* bounce max_depth has been shaded: poll whether anything (null-material pass-throughs) is left */
                 if (!polled) {
@@ -1217,7 +1142,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     }
     rc = flush_events(); if (rc) return rc;
     WF_TRY(hipGetLastError());
-    if (times) { times->trace_ms = trace_ms; times->trace_launches = trace_launches; times->mis_any_rays = mis_any_rays; }
+    if (times) {
+        times->trace_ms = trace_ms; times->trace_launches = trace_launches; times->mis_any_rays = mis_any_rays;
+        times->any_ms = group_ms[1]; times->any_launches = group_n[1]; times->shade_ms = group_ms[2]; times->shade_launches = group_n[2]; times->sort_ms = group_ms[3];
+    }
     return FTN_OK;
 }
 

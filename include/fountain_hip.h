@@ -282,6 +282,13 @@ typedef struct ftn_stats {
     uint64_t prims_tested_any;
     uint64_t mis_rays_any_hit;  /* Scene::intersect calls of estimate_direct (integrator/mod.rs:367) answered by the any-hit kernel: toward an
                                    infinite light only hit / miss matters.  Included in rays_closest (the reference's accounting).      */
+    uint64_t quad_records;      /* count_traffic = 2: 128-byte four-box records fetched by the production traversal kernels (both) */
+    uint64_t quad_records_any;  /*                    ... the any-hit kernel's share                                               */
+    double any_ms;              /* device time of the any-hit traversal launches (wavefront)                                       */
+    uint64_t any_launches;
+    double shade_ms;            /* device time of the classify + shade launches (wavefront)                                        */
+    uint64_t shade_launches;    /* bounces shaded                                                                                  */
+    double sort_ms;             /* device time of the ray-queue coherence sorts (wavefront)                                        */
 } ftn_stats;
 
 /* ------------------------------------------------------------------ host-side constructors
@@ -336,6 +343,11 @@ void ftn_scene_destroy(ftn_scene* scene);
  * Returns the node count in *n_nodes_out.                                                       */
 int ftn_bvh_build(const ftn_scene_desc* desc, ftn_bvh_node* nodes_out, uint32_t* prim_order_out,
                   uint32_t* n_nodes_out, uint32_t* max_depth_out);
+
+/* The four-box view of a flattened BVH that the traversal kernels walk (host only, no device needed): one
+ * record of 32 floats (128 bytes) per two levels of the tree `nodes` (as returned by ftn_bvh_build; reference layout bvh.rs:269-302).
+ * records_out: capacity 32 * (number of interior nodes) floats, or NULL to query the counts. */
+int ftn_bvh_quads(const ftn_bvh_node* nodes, uint32_t n_nodes, float* records_out, uint32_t* n_records_out, uint32_t* stack_bound_out);
 
 /* Introspection for parity tests. */
 int ftn_scene_info(const ftn_scene* scene, uint32_t* n_nodes, uint32_t* n_prims, uint32_t* n_lights,

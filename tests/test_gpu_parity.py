@@ -496,3 +496,79 @@ def test_wavefront_paths_deeper_than_255_bounces(gpu, orc_det):
     assert_film_equal(pg, po, sg["spill_samples"], "furnace, depth 300")
     with pytest.raises(FountainError):
         scenes.render(gpu, *scenes.furnace(gpu, res=16), PathIntegrator(70000, 0.0), smp, backend_kwargs=dict(pipeline=WAVE))
+
+
+# ------------------------------------------------------------------ production traversal kernels (four-box records, ftn_trace4.hip)
+def _ray_mix(n, seed, lo=-30.0, hi=30.0):
+    """random rays + the exceptional ones: axis-parallel directions (exact zeros, negative zeros) from origins on round coordinates"""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = unit_dirs(n, seed + 1) * rng.uniform(0.1, 40, (n, 1)).astype(np.float32)
+    k = n // 8
+    d[:k, 0] = 0.0
+    d[k // 2:k, 1] = -0.0
+    d[k:k + k // 2] = np.array([0.0, 0.0, -1.0], np.float32)
+    o[:k] = np.round(o[:k])
+    o[k:k + k // 2, 2] = 25.0
+    t_max = rng.choice([np.inf, 1.0 - 1e-4, 0.5], n).astype(np.float32)
+    return make_rays(o, d, t_max=t_max)
+
+
+@pytest.mark.parametrize("scene", ["cube", "cubes27", "cornell"])
+def test_four_box_kernels_equal_the_oracle_on_ray_batches(gpu, orc_det, scene):
+    """ftn_intersect / ftn_intersect_test without statistics run the production kernels (k_wf_trace4 / k_wf_trace4_any over 128-byte
+    four-box records; rays with a zero direction component are handed to the reference-order kernel): t, primitive, barycentrics and
+    occlusion bit-equal to the oracle's and to the counting build of the reference walk."""
+    if scene == "cube":
+        sg, so = cube_scene(gpu), cube_scene(orc_det)
+    elif scene == "cubes27":
+        sg, so = (scenes.instanced_cubes(be, n_copies=27, res=(16, 16), env_n=8, spacing=14.0)[0].create_scene() for be in (gpu, orc_det))
+    else:
+        sg, so = (scenes.cornell(be, res=16)[0].create_scene() for be in (gpu, orc_det))
+    lo, hi = (-30.0, 30.0) if scene != "cornell" else (-1.5, 1.5)
+    rays = _ray_mix(60000, 21, lo, hi)
+    if scene == "cornell":
+        rays[:, 3:6] *= 0.05
+    t, prim, bary, none = sg.intersect(rays, stats=False)
+    assert none is None
+    tc, pc, bc, stc = sg.intersect(rays)
+    to, po, bo, sto = so.intersect(rays)
+    assert 0 < (po >= 0).sum() < len(po)
+    assert np.array_equal(bits(t), bits(to)) and np.array_equal(prim, po)
+    assert np.array_equal(bits(tc), bits(to)) and np.array_equal(pc, po) and stc["nodes_visited"] == sto["nodes_visited"]
+    assert np.array_equal(bits(bary), bits(bc))          # (the oracle's intersect does not return barycentrics: the full records below pin them)
+    occ, _ = sg.intersect_test(rays, stats=False)
+    occ_o, _ = so.intersect_test(rays)
+    assert np.array_equal(occ, occ_o) and 0 < occ.sum() < len(occ)
+    full_g, full_o = sg.intersect_full(rays[:8000]), so.intersect_full(rays[:8000])
+    assert np.array_equal(bits(full_g[:, :9]), bits(full_o[:, :9])) and np.array_equal(bits(full_g[:, 20:24]), bits(full_o[:, 20:24]))
+
+
+def test_four_box_kernels_render_like_the_two_record_kernels(gpu, orc_det, monkeypatch):
+    """the same render with the four-box kernels (default), with a two-level LDS stack (nearly every push spills to global memory), and
+    with FTN_TRACE4=0 (round 1's kernels): one film, one set of counters; and it is the oracle's film"""
+    make = lambda be: scenes.instanced_cubes(be, n_copies=27, res=(160, 160), env_n=32)
+    b, cam, res = make(gpu)
+    sc = b.create_scene()
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    films, stats = [], []
+    for env in ({}, {"FTN_T4_ENTRIES": "2", "FTN_T4_ENTRIES_ANY": "2"}, {"FTN_T4_BURST": "4", "FTN_T4_WG": "3"}, {"FTN_TRACE4": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        f = Film(gpu, res)
+        stats.append(si.render_parallel(sc, f, RandomSampler(2, 0, indexed=True), pipeline=WAVE, count_traffic=2))
+        films.append(f.pixels)
+        for k in env:
+            monkeypatch.delenv(k)
+    for k in range(1, 4):
+        assert np.array_equal(bits(films[0]), bits(films[k])), k
+        for c in ("rays_closest", "rays_any", "camera_samples", "mis_rays_any_hit"):
+            assert stats[0][c] == stats[k][c], (k, c)
+    assert stats[0]["quad_records"] == stats[1]["quad_records"] > 0 and stats[3]["quad_records"] == 0
+    # one 128-byte record fetch decides two levels: fewer fetches than the two-record walk visits nodes
+    assert stats[0]["quad_records"] * 2 < stats[3]["nodes_visited"]
+    bo, camo, _ = make(orc_det)
+    fo = Film(orc_det, res)
+    sto = SamplerIntegrator(camo, PathIntegrator.new(5, 1.0)).render_parallel(bo.create_scene(), fo, RandomSampler(2, 0, indexed=True))
+    assert_film_equal(films[0], fo.pixels, stats[0]["spill_samples"], "four-box kernels vs oracle")
+    assert sto["rays_closest"] == stats[0]["rays_closest"] and sto["rays_any"] == stats[0]["rays_any"]
