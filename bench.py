@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--dist-backend", default=os.environ.get("FTN_BENCH_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI, one GPU per rank (the measured configuration); gloo = rehearsal of the N-rank path (see --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank renders on GPU 0, films merged over gloo on the host")
+    ap.add_argument("--no-count-step", action="store_true", help="skip the untimed counting step (tools/make_traffic_json.py: every dispatch of the run then belongs to the timed steps)")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, form the process group, print the result line's n_gpus -- no rendering (CPU test of the launcher)")
     args = ap.parse_args()
 
@@ -115,7 +116,7 @@ def main():
     # one counted step: algorithmic bytes of the dominant kernel (nodes / triangles per ray are data dependent: SURVEY 8(d)).
     # count_traffic = 2: tally exactly the rays each kernel traces in production (MIS rays toward the environment light only need
     # hit / miss and go through the any-hit kernel: ftn_stats.mis_rays_any_hit)
-    cst = step(0, count=2)
+    cst = step(0, count=2) if not args.no_count_step else None
     dev_film.zero_()
     for i in range(args.warmup):
         step(i)
@@ -133,17 +134,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     rays = 0
-    trace_ms = 0.0
-    trace_launches = 0
-    kernel_ms = 0.0
-    cam_samples = 0
+    tot = {"trace_ms": 0.0, "trace_launches": 0, "any_ms": 0.0, "any_launches": 0, "shade_ms": 0.0, "shade_launches": 0, "sort_ms": 0.0, "kernel_ms": 0.0, "camera_samples": 0}
     for i in range(args.steps):
         st = step(args.warmup + i)
         rays += st["rays_closest"] + st["rays_any"]
-        trace_ms += st["trace_ms"]
-        trace_launches += st["trace_launches"]
-        kernel_ms += st["kernel_ms"]
-        cam_samples += st["camera_samples"]
+        for k in tot:
+            tot[k] += st[k]
+    cam_samples = tot["camera_samples"]
     merge()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -157,47 +154,101 @@ def main():
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
-        # ---- roofline of the dominant kernel, k_wf_trace<closest>: algorithmic bytes / its launches' device time
-        nodes_c = cst["nodes_visited"] - cst["nodes_visited_any"]
-        prims_c = cst["prims_tested"] - cst["prims_tested_any"]
-        rays_c = cst["rays_closest"] - cst["mis_rays_any_hit"]          # rays the closest-hit launches traced
-        bytes_per_step = 32.0 * nodes_c + 48.0 * prims_c + (32.0 + 16.0) * rays_c
-        launches_per_step = max(cst["trace_launches"], 1)
-        bytes_per_launch = bytes_per_step / launches_per_step
-        avg_launch_ms = trace_ms / max(trace_launches, 1)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        n_steps = max(args.steps, 1)
         out = {
             "metric": "Mrays/s (primary+secondary) at fixed spp", "value": round(mrays, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / n_steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config 5 scene: %d baked copies of rounded_cube = %d triangles (%d BVH nodes, depth %d), %dx%d film, "
                                    "PathIntegrator(max_depth 5, rr 1.0), 1024^2 env-map light; one step = %d spp over the whole film"
                                    % (args.copies, info["n_prims"], info["n_nodes"], info["max_depth"], res[0], res[1], spp_per_step),
-                       "tiles": n_tiles, "tiles_per_gpu": (n_tiles + world - 1) // world, "camera_samples_per_step": cam_samples // max(args.steps, 1),
-                       "rays_per_step": rays // max(args.steps, 1), "pipeline": "wavefront", "sampler": "indexed xoshiro256+",
-                       "scene_build_s": round(build_s, 1), "device_ms_per_step": round(kernel_ms / max(args.steps, 1), 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_wf_trace<closest>", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_launch_ms, 4),
-                         "launches_per_step": int(launches_per_step), "rays_per_launch": int(rays_c // launches_per_step),
-                         "nodes_per_ray": round(nodes_c / max(rays_c, 1), 2), "prims_per_ray": round(prims_c / max(rays_c, 1), 3),
-                         "note": "algorithmic bytes (32 B per node visit + 48 B per triangle test + ray i/o: SURVEY 8(d)) over the launch time; "
-                                 "most node fetches are L2 / L1 hits, so the figure can exceed the HBM peak -- `traffic` is the HBM-side byte count "
-                                 "of the same launch from PMC counters"},
+                       "tiles": n_tiles, "tiles_per_gpu": (n_tiles + world - 1) // world, "camera_samples_per_step": cam_samples // n_steps,
+                       "rays_per_step": rays // n_steps, "pipeline": "wavefront", "sampler": "indexed xoshiro256+",
+                       "per_gpu_workload": per_gpu_workload(args), "scene_build_s": round(build_s, 1), "device_ms_per_step": round(tot["kernel_ms"] / n_steps, 3)},
+            "roofline": roofline(args, cst, tot, n_steps, spp_per_step),
         }
-        # HBM-side traffic of the same kernel from PMC counters (collected offline with rocprofv3, see profiles/r01_traffic.json)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("workload") == "copies=%d,res=%d,spp_per_step=%d" % (args.copies, args.res, spp_per_step):
-                out["roofline"]["traffic"] = int(tj["traffic_bytes_per_launch"])
-                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam, film, args.cpu_tiles, n_tiles)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def per_gpu_workload(args):
+    return "copies=%d,res=%d,spp_per_gpu=%d" % (args.copies, args.res, max(1, args.spp_per_gpu))
+
+
+def source_hash():
+    """hash of the kernel sources the PMC profile was taken on (same list as tools/make_traffic_json.py)"""
+    import hashlib
+    tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
+    try:
+        srcs = json.load(open(tj))["sources"]
+    except Exception:
+        return None
+    h = hashlib.sha256()
+    for rel in srcs:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PROFILE_ROUND = "r02"
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def roofline(args, cst, tot, n_steps, spp_per_step):
+    """The dominant kernel (k_wf_trace4<closest>) against the HBM roof, three ways that must not be mixed up:
+      * achieved / frac / traffic: bytes that really cross the HBM interface per launch -- from PMC counters, collected OFFLINE over this same
+        command by tools/make_traffic_json.py (profiles/<round>/traffic.json, used only while the kernel sources still hash to what was
+        profiled) -- divided by the launch duration measured LIVE in this run (HIP events on the launch stream).  frac <= 1 by construction;
+      * algorithmic: bytes the walk asks the memory system for (128 B per four-box record + 48 B per triangle + ray i/o; SURVEY 8(d) restated
+        for the records this kernel reads), most of which L1 / L2 serve -- a rate above the HBM peak only says the caches work;
+      * what binds: the PMC passes show the VALU pipes busy most of the launch and the HBM interface at a small fraction (valu_busy,
+        wave_cycles_waiting_on_memory) -- the kernel is instruction-issue bound, not bandwidth bound.
+    The same three figures are given for the other kernel groups of a step and for the step as a whole."""
+    avg_ms = tot["trace_ms"] / max(tot["trace_launches"], 1)
+    r = {"bound": "hbm", "kernel": "k_wf_trace4<closest> (128-byte four-box records)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": tot["trace_launches"] // n_steps}
+    if cst is not None:
+        rec_c = cst["quad_records"] - cst["quad_records_any"]
+        prims_c = cst["prims_tested"] - cst["prims_tested_any"]
+        rays_c = cst["rays_closest"] - cst["mis_rays_any_hit"]          # rays the closest-hit launches traced
+        launches = max(cst["trace_launches"], 1)
+        alg = (128.0 * rec_c + 48.0 * prims_c + (32.0 + 16.0) * rays_c) / launches
+        r["algorithmic"] = {"bytes_per_launch": int(alg), "GB_per_s": round(alg / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+                            "records_per_ray": round(rec_c / max(rays_c, 1), 2), "prims_per_ray": round(prims_c / max(rays_c, 1), 3), "rays_per_launch": int(rays_c // launches),
+                            "note": "128 B per four-box record + 48 B per triangle test + 48 B of ray i/o; served mostly by L1 / L2, hence not a fraction of the HBM roof"}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))
+    except Exception:
+        tj = None
+    # the profile is of ONE GPU's share of a step (N-GPU runs give every GPU the same share: --spp-per-gpu samples of its tiles)
+    same_work = tj is not None and tj.get("per_gpu_workload") == per_gpu_workload(args)
+    if tj is None or tj.get("source_hash") != source_hash() or not same_work:
+        r["note"] = "no PMC profile of this build / workload under profiles/%s (run tools/make_traffic_json.py on the GPU box): HBM-side figures omitted" % PROFILE_ROUND
+        return r
+    dk = tj["dominant_kernel"]
+    r["traffic"] = int(dk["hbm_bytes_per_launch"])
+    r["achieved"] = round(dk["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None
+    r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4) if r["achieved"] is not None else None
+    r["l2_hit_rate"] = round(dk["l2_hit_rate"], 3)
+    r["valu_busy"] = round(dk["valu_busy"], 3) if dk.get("valu_busy") is not None else None
+    r["wave_cycles_waiting_on_memory"] = round(dk["wave_cycles_waiting_on_memory"], 3) if dk.get("wave_cycles_waiting_on_memory") is not None else None
+    r["binds"] = "VALU issue (valu_busy), not HBM: see DESIGN.md section 5"
+    r["traffic_source"] = "profiles/%s/traffic.json (rocprofv3 --pmc over this command, production kernels only; FETCH_SIZE x 2 + WRITE_SIZE, cross-checked with TCC_EA0_RDREQ_128B x 128 B)" % PROFILE_ROUND
+    live = {"closest": tot["trace_ms"] / n_steps, "any_hit": tot["any_ms"] / n_steps, "shade": tot["shade_ms"] / n_steps, "sort": tot["sort_ms"] / n_steps}
+    groups = {}
+    step_bytes = 0.0
+    for g, v in tj["groups"].items():
+        step_bytes += v["hbm_bytes_per_step"]
+        ms = live.get(g)
+        groups[g] = {"ms_per_step": round(ms, 2) if ms is not None else None, "hbm_GB_per_step": round(v["hbm_bytes_per_step"] / 1e9, 2),
+                     "hbm_frac": round(v["hbm_bytes_per_step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None, "l2_hit_rate": round(v["l2_hit_rate"], 3),
+                     "valu_busy": round(v["valu_busy"], 3) if v.get("valu_busy") is not None else None}
+    r["groups"] = groups
+    step_ms = tot["kernel_ms"] / n_steps
+    r["whole_step"] = {"device_ms": round(step_ms, 2), "hbm_GB": round(step_bytes / 1e9, 1), "hbm_frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_ms > 0 else None}
+    return r
 
 
 def cpu_baseline(desc, cam, film, n_cpu_tiles, n_tiles):

@@ -572,3 +572,20 @@ def test_four_box_kernels_render_like_the_two_record_kernels(gpu, orc_det, monke
     sto = SamplerIntegrator(camo, PathIntegrator.new(5, 1.0)).render_parallel(bo.create_scene(), fo, RandomSampler(2, 0, indexed=True))
     assert_film_equal(films[0], fo.pixels, stats[0]["spill_samples"], "four-box kernels vs oracle")
     assert sto["rays_closest"] == stats[0]["rays_closest"] and sto["rays_any"] == stats[0]["rays_any"]
+
+
+def test_furnace_path_no_rr_on_the_wavefront_pipeline(gpu, orc_det):
+    """tests/furnace.rs `path_no_rr` (PathIntegrator(10, 0.0) in the albedo-0.5 furnace) on the pipeline the bench times, with the indexed
+    sampler stream.  With max_depth 10 the estimator's mean is 2 - 2^-10 (the series 1 + 1/2 + 1/4 + ... is cut after ten scattering
+    terms), which sits 2.3e-5 inside the reference's +-0.001 window around 2.0 -- the reference's assertion holds for its own stream at
+    128 spp but is no statement about another stream's Monte-Carlo noise.  So: 1024 spp (noise ~3e-5 per pixel), every pixel within
+    +-0.001 of the true mean 2 - 2^-10 and the image mean within 1e-4 of it; bit-exact against the oracle; every path takes all 11 segments."""
+    integ, smp = PathIntegrator.new(10, 0.0), RandomSampler(1024, 0, indexed=True)
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, scenes.furnace, integ, smp, WAVE)
+    mean = 2.0 - 2.0 ** -10
+    assert np.abs(rgb - mean).max() <= 0.001, float(np.abs(rgb - mean).max())
+    assert abs(float(rgb.mean()) - mean) <= 1e-4 and np.abs(rgb - 2.0).max() <= 0.002
+    assert_film_equal(px, pxo, st["spill_samples"], "furnace path_no_rr, wavefront")
+    assert st["rays_closest"] == sto["rays_closest"] == 16 * 16 * 1024 * 11 and st["rays_any"] == sto["rays_any"]
+    prod = scenes.render(gpu, *scenes.furnace(gpu), integ, smp, backend_kwargs=dict(pipeline=WAVE))     # production kernels (no counting build)
+    assert np.array_equal(bits(prod[1]), bits(px))
