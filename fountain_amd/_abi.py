@@ -45,7 +45,7 @@ class ftn_prim(C.Structure):
 
 
 class ftn_mesh(C.Structure):
-    _fields_ = [("has_normals", c_u32), ("has_uvs", c_u32), ("flip_normals", c_u32), ("reverse_orientation", c_u32)]
+    _fields_ = [("has_normals", c_u32), ("has_uvs", c_u32), ("flip_normals", c_u32), ("reverse_orientation", c_u32), ("has_tangents", c_u32)]
 
 
 class ftn_sphere(C.Structure):
@@ -98,6 +98,7 @@ class ftn_scene_desc(C.Structure):
         ("n_envmaps", c_u32), ("envmaps", C.POINTER(ftn_envmap)),
         ("n_textures", c_u32), ("textures", C.POINTER(ftn_texture)), ("material_textures", C.POINTER(ftn_material_textures)),
         ("n_images", c_u32), ("images", C.POINTER(ftn_image)),
+        ("S", C.POINTER(c_f)),
     ]
 
 
@@ -141,7 +142,7 @@ class ftn_stats(C.Structure):
 
 # Expected sizes (bytes) -- asserted against the header by the C side's static_asserts and tests/test_abi.py
 SIZES = {
-    "ftn_transform": 128, "ftn_pixel": 16, "ftn_bvh_node": 32, "ftn_prim": 16, "ftn_mesh": 16,
+    "ftn_transform": 128, "ftn_pixel": 16, "ftn_bvh_node": 32, "ftn_prim": 16, "ftn_mesh": 20,
     "ftn_sphere": 288, "ftn_material": 48, "ftn_light": 160, "ftn_envmap": 16, "ftn_camera_desc": 296,
     "ftn_film_desc": 32, "ftn_sampler_desc": 24, "ftn_integrator_desc": 16, "ftn_tile_range": 16,
     "ftn_render_options": 16, "ftn_stats": 152, "ftn_texture": 48, "ftn_image": 24, "ftn_material_textures": 32,

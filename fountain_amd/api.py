@@ -265,8 +265,10 @@ class SceneBuilder:
         self.P = []
         self.N = []
         self.UV = []
+        self.S = []              # per-vertex shading tangents (zeros for meshes without)
         self.any_normals = False
         self.any_uvs = False
+        self.any_tangents = False
         self.n_vertices = 0
         self.n_triangles = 0
         self.meshes = []
@@ -446,15 +448,18 @@ class SceneBuilder:
                 N = np.asarray(kw["N"], dtype=np.float32).reshape(-1, 3) if kw.get("N") is not None else None
                 UV = np.asarray(kw["uv"], dtype=np.float32).reshape(-1, 2) if kw.get("uv") is not None else None
                 idx = np.asarray(kw["indices"], dtype=np.uint32).reshape(-1, 3)
-            self.add_mesh(P, N, UV, idx, tf, st["rev"], st["material"], st["area"])
+            S = np.asarray(kw["S"], dtype=np.float32).reshape(-1, 3) if kw.get("S") is not None else None      # constructors.rs:63
+            self.add_mesh(P, N, UV, idx, tf, st["rev"], st["material"], st["area"], S=S)
         else:
             raise ValueError("unknown shape " + name)
 
-    def add_mesh(self, P, N, UV, idx, tf, rev, material, area):
-        """TriangleMesh::new (src/shapes/triangle.rs:29-74): vertices and normals go to world space."""
+    def add_mesh(self, P, N, UV, idx, tf, rev, material, area, S=None):
+        """TriangleMesh::new (src/shapes/triangle.rs:29-74): vertices, normals and tangents go to world space."""
         Pw = tf.points(P)
         Nw = tf.normals(N) if N is not None else None
+        Sw = np.stack([tf.vector(t) for t in S]).astype(np.float32) if S is not None else None
         m = A.ftn_mesh()
+        m.has_tangents = 1 if S is not None else 0
         m.has_normals = 1 if N is not None else 0
         m.has_uvs = 1 if UV is not None else 0
         m.reverse_orientation = 1 if rev else 0
@@ -466,6 +471,8 @@ class SceneBuilder:
         self.P.append(Pw)
         self.N.append(Nw if Nw is not None else np.zeros((nv, 3), np.float32))
         self.UV.append(UV if UV is not None else np.zeros((nv, 2), np.float32))
+        self.S.append(Sw if Sw is not None else np.zeros((nv, 3), np.float32))
+        self.any_tangents |= S is not None
         self.any_normals |= N is not None
         self.any_uvs |= UV is not None
         self.n_vertices += nv
@@ -546,7 +553,8 @@ class SceneBuilder:
         P = np.ascontiguousarray(np.concatenate(self.P)) if self.P else np.zeros((0, 3), np.float32)
         N = np.ascontiguousarray(np.concatenate(self.N)) if self.N else np.zeros((0, 3), np.float32)
         UV = np.ascontiguousarray(np.concatenate(self.UV)) if self.UV else np.zeros((0, 2), np.float32)
-        keep += [ti, tm, P, N, UV]
+        S = np.ascontiguousarray(np.concatenate(self.S)) if self.S else np.zeros((0, 3), np.float32)
+        keep += [ti, tm, P, N, UV, S]
         d.n_triangles = ti.shape[0]
         d.tri_indices = ti.ctypes.data_as(C.POINTER(C.c_uint32))
         d.tri_mesh = tm.ctypes.data_as(C.POINTER(C.c_uint32))
@@ -554,6 +562,7 @@ class SceneBuilder:
         d.P = _fptr(P)
         d.N = _fptr(N) if self.any_normals else None
         d.UV = _fptr(UV) if self.any_uvs else None
+        d.S = _fptr(S) if self.any_tangents else None
         for name, items, typ in (("meshes", self.meshes, A.ftn_mesh), ("spheres", self.spheres, A.ftn_sphere),
                                  ("materials", self.materials, A.ftn_material), ("lights", self.lights, A.ftn_light)):
             arr = (typ * max(len(items), 1))(*items)

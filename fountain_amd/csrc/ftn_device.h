@@ -29,7 +29,7 @@ namespace ftn {
 
 #define FTN_DEV_NOINLINE __device__ inline   /* out-of-line variants were measured slower (see detmath.h) */
 
-enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u, GF_LEAF_END = 16u /* last primitive of its BVH leaf */ };
+enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u, GF_LEAF_END = 16u /* last primitive of its BVH leaf */, GF_HAS_TANGENTS = 32u /* per-vertex shading tangents in DScene::T */ };
 enum : uint32_t { LK_POINT = 0, LK_DISTANT = 1, LK_INFINITE = 2, LK_AREA = 3 };
 
 struct DSphere {
@@ -65,6 +65,7 @@ struct DImage { uint32_t w, h, wrap, n_levels; uint32_t off[16], lw[16], lh[16];
 struct DScene {
     const float4* nodes; const float4* geom; const uint4* prim_info;
     const float* N; const float* UV;
+    const float* T;                         /* per-vertex shading tangents ("S", triangle.rs:341-347) or NULL; gathered through prim_info's vertex indices */
     const DSphere* spheres; const ftn_material* materials; const DLight* lights;
     uint32_t n_nodes, n_prims, n_lights, n_inf_lights, n_spheres, _pad;
     const uint32_t* inf_lights;             /* indices of infinite lights (environment_emitted_radiance sums all lights) */
@@ -422,16 +423,22 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
     V3 sn = n;
     if (fl & GF_FLIP) { n = n * -1.0f; sn = sn * -1.0f; }
     si->s_dpdu = dpdu;
-    if (fl & GF_HAS_NORMALS) {
-        V3 ns = normalize(b0 * n0 + b1 * n1 + b2 * n2);
-        V3 ss = normalize(dpdu);
+    if (fl & (GF_HAS_NORMALS | GF_HAS_TANGENTS)) {               /* triangle.rs:332-391 */
+        V3 ns = n;                                               /* no normals: the (already flipped) geometric normal, triangle.rs:337 */
+        if (fl & GF_HAS_NORMALS) ns = normalize(b0 * n0 + b1 * n1 + b2 * n2);
+        V3 ss;
+        if (fl & GF_HAS_TANGENTS) {                              /* the mesh's interpolated tangent instead of dpdu, triangle.rs:341-342 */
+            const uint4 vi = S.prim_info[2 * h.prim + 1]; const float* T = S.T;
+            const V3 t0(T[3 * vi.x], T[3 * vi.x + 1], T[3 * vi.x + 2]), t1(T[3 * vi.y], T[3 * vi.y + 1], T[3 * vi.y + 2]), t2(T[3 * vi.z], T[3 * vi.z + 1], T[3 * vi.z + 2]);
+            ss = normalize(b0 * t0 + b1 * t1 + b2 * t2);
+        } else ss = normalize(dpdu);
         V3 ts = cross(ns, ss);
         if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
         else coordinate_system(ns, &ts, &ss);      /* (v2, v3) bound as (ts, ss): triangle.rs:343-349 */
         si->s_dpdu = ss;
         sn = ns;
         n = faceforward(n, sn);
-        if (ex) {                                                /* triangle.rs:351-366 */
+        if (ex && (fl & GF_HAS_NORMALS)) {                       /* triangle.rs:351-366 (a mesh with tangents only keeps dndu = dndv = 0, :367-369) */
             const V3 dn1 = n0 - n2, dn2 = n1 - n2;
             if (degenerate_uv) {
                 const V3 dn = cross(n2 - n0, n1 - n0);

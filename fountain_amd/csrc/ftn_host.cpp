@@ -27,7 +27,7 @@
 using namespace ftn;
 
 static_assert(sizeof(ftn_transform) == 128 && sizeof(ftn_pixel) == 16 && sizeof(ftn_bvh_node) == 32 && sizeof(ftn_prim) == 16, "ABI");
-static_assert(sizeof(ftn_mesh) == 16 && sizeof(ftn_sphere) == 288 && sizeof(ftn_material) == 48 && sizeof(ftn_light) == 160, "ABI");
+static_assert(sizeof(ftn_mesh) == 20 && sizeof(ftn_sphere) == 288 && sizeof(ftn_material) == 48 && sizeof(ftn_light) == 160, "ABI");
 static_assert(sizeof(ftn_envmap) == 16 && sizeof(ftn_camera_desc) == 296 && sizeof(ftn_film_desc) == 32 && sizeof(ftn_sampler_desc) == 24, "ABI");
 static_assert(sizeof(ftn_integrator_desc) == 16 && sizeof(ftn_tile_range) == 16 && sizeof(ftn_render_options) == 16 && sizeof(ftn_stats) == 152, "ABI");
 
@@ -446,6 +446,7 @@ static int validate_desc(const ftn_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_meshes; i++) {
         if (d->meshes[i].has_normals && !d->N) return fail(FTN_ERR_INVALID_ARGUMENT, "a mesh has normals but N is NULL");
         if (d->meshes[i].has_uvs && !d->UV) return fail(FTN_ERR_INVALID_ARGUMENT, "a mesh has uvs but UV is NULL");
+        if (d->meshes[i].has_tangents && !d->S) return fail(FTN_ERR_INVALID_ARGUMENT, "a mesh has tangents but S is NULL");
     }
     for (uint32_t i = 0; i < d->n_envmaps; i++) if (!d->envmaps[i].texels) return fail(FTN_ERR_INVALID_ARGUMENT, "environment map without texels");
     if (d->n_textures && d->textures) {                        /* textures */
@@ -603,7 +604,7 @@ struct ftn_scene {
     int device = 0;
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
-    DevBuf<float4> nodes, geom, fat, srec, quad; DevBuf<uint4> prim_info; DevBuf<float> N, UV; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
+    DevBuf<float4> nodes, geom, fat, srec, quad; DevBuf<uint4> prim_info; DevBuf<float> N, UV, T; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
     DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
@@ -612,7 +613,7 @@ struct ftn_scene {
     WavefrontState* wf = nullptr;
     std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
-        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); prim_info.release(); N.release(); UV.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
+        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); prim_info.release(); N.release(); UV.release(); T.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
         for (auto& b : misc) b.release();
         for (auto& b : misc4) b.release();
         textures.release(); mtex.release(); images.release(); texels.release();
@@ -667,6 +668,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             const ftn_mesh& m = d->meshes[d->tri_mesh[p.shape_index]];
             if (m.has_normals && d->N) fl |= GF_HAS_NORMALS;
             if (m.has_uvs && d->UV) fl |= GF_HAS_UVS;
+            if (m.has_tangents && d->S) fl |= GF_HAS_TANGENTS;
             if (m.flip_normals) fl |= GF_FLIP;
             if (leaf_end[i]) fl |= GF_LEAF_END;
             const uint32_t* vi = d->tri_indices + 3 * (size_t)p.shape_index;
@@ -720,6 +722,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     }
     if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
     if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
+    if (d->S && (rc = sc->T.upload(d->S, 3 * (size_t)d->n_vertices))) return rc;
     std::vector<DSphere> sph(d->n_spheres);
     for (uint32_t i = 0; i < d->n_spheres; i++) {
         const ftn_sphere& s = d->spheres[i]; DSphere& o = sph[i];
@@ -817,7 +820,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     if ((rc = sc->lights.upload(lights.data(), lights.size()))) return rc;
     if ((rc = sc->inf_lights.upload(inf.data(), inf.size()))) return rc;
     DScene& D = sc->d; memset(&D, 0, sizeof(D));
-    D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.spheres = sc->spheres.p;
+    D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.T = sc->T.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
     D.srec = sc->srec.p;

@@ -51,7 +51,7 @@ struct Lexer {
     }
 };
 
-struct Mesh { std::vector<float> P, N, UV; std::vector<uint32_t> idx; };
+struct Mesh { std::vector<float> P, N, UV, S; std::vector<uint32_t> idx; };
 
 struct GState { int material; int area; bool rev; };
 
@@ -65,7 +65,7 @@ struct ftn_pbrt {
     /* world */
     std::vector<GState> gs; std::vector<ftn_transform> tf;
     std::map<std::string, int> named_materials;
-    std::vector<ftn_prim> prims; std::vector<uint32_t> tri_indices, tri_mesh; std::vector<float> P, N, UV; bool any_n = false, any_uv = false;
+    std::vector<ftn_prim> prims; std::vector<uint32_t> tri_indices, tri_mesh; std::vector<float> P, N, UV, T; bool any_n = false, any_uv = false, any_t = false;
     std::vector<ftn_mesh> meshes; std::vector<ftn_sphere> spheres; std::vector<ftn_material> materials; std::vector<float> area_emit;
     std::vector<ftn_texture> textures; std::vector<ftn_material_textures> mtex; std::map<std::string, int> spectrum_textures, float_textures;
     struct Img { uint32_t w, h, wrap; std::vector<float> texels; }; std::vector<Img> image_store; std::vector<ftn_image> images;
@@ -280,10 +280,11 @@ int add_texture(ftn_pbrt* S, const std::string& name, std::string ty, const std:
 int add_mesh(ftn_pbrt* S, const Mesh& m) {      /* TriangleMesh::new (triangle.rs:29-74) + one GeometricPrimitive per triangle */
     const ftn_transform& tf = S->tf.back(); const GState& g = S->gs.back();
     const size_t nv = m.P.size() / 3, base = S->P.size() / 3;
-    ftn_mesh fm; fm.has_normals = m.N.empty() ? 0 : 1; fm.has_uvs = m.UV.empty() ? 0 : 1; fm.reverse_orientation = g.rev ? 1 : 0;
+    ftn_mesh fm; fm.has_normals = m.N.empty() ? 0 : 1; fm.has_uvs = m.UV.empty() ? 0 : 1; fm.reverse_orientation = g.rev ? 1 : 0; fm.has_tangents = m.S.empty() ? 0 : 1;
     fm.flip_normals = (g.rev != (ftn_transform_swaps_handedness(&tf) != 0)) ? 1 : 0;
     S->meshes.push_back(fm);
-    S->P.resize(3 * (base + nv)); S->N.resize(3 * (base + nv), 0.0f); S->UV.resize(2 * (base + nv), 0.0f);
+    S->P.resize(3 * (base + nv)); S->N.resize(3 * (base + nv), 0.0f); S->UV.resize(2 * (base + nv), 0.0f); S->T.resize(3 * (base + nv), 0.0f);
+    if (!m.S.empty()) { for (size_t v = 0; v < nv; v++) ftn_transform_vector(&tf, m.S.data() + 3 * v, S->T.data() + 3 * (base + v)); S->any_t = true; }      /* triangle.rs:53-58 */
     ftn_transform_points(&tf, nv, m.P.data(), S->P.data() + 3 * base);
     if (!m.N.empty()) { ftn_transform_normals(&tf, nv, m.N.data(), S->N.data() + 3 * base); S->any_n = true; }
     if (!m.UV.empty()) { memcpy(S->UV.data() + 2 * base, m.UV.data(), m.UV.size() * 4); S->any_uv = true; }
@@ -437,9 +438,9 @@ int parse(ftn_pbrt* S, const std::string& path) {
                 if (m.idx.size() % 3) return fail(S, FTN_ERR_INVALID_ARGUMENT, "indices is not a multiple of 3");
                 m.P = ip->second.f;
                 if (ps.find("N") != ps.end()) m.N = ps["N"].f;
-                if (ps.find("S") != ps.end()) return fail(S, FTN_ERR_UNSUPPORTED, "vertex tangents (S) are not supported");
+                if (ps.find("S") != ps.end()) m.S = ps["S"].f;                 /* constructors.rs:63 */
                 if (ps.find("uv") != ps.end()) m.UV = ps["uv"].f; else if (ps.find("st") != ps.end()) m.UV = ps["st"].f;
-                if ((!m.N.empty() && m.N.size() != m.P.size()) || (!m.UV.empty() && m.UV.size() / 2 != m.P.size() / 3)) return fail(S, FTN_ERR_INVALID_ARGUMENT, "per-vertex array length mismatch");
+                if ((!m.N.empty() && m.N.size() != m.P.size()) || (!m.S.empty() && m.S.size() != m.P.size()) || (!m.UV.empty() && m.UV.size() / 2 != m.P.size() / 3)) return fail(S, FTN_ERR_INVALID_ARGUMENT, "per-vertex array length mismatch");
                 if ((rc = add_mesh(S, m))) return rc;
             } else if (type == "plymesh") {
                 auto it = ps.find("filename"); if (it == ps.end() || it->second.s.empty()) return fail(S, FTN_ERR_INVALID_ARGUMENT, "plymesh needs a filename");
@@ -472,7 +473,7 @@ int parse(ftn_pbrt* S, const std::string& path) {
     for (auto& e : S->env_store) { ftn_envmap m; m.width = e.w; m.height = e.h; m.texels = e.texels.data(); S->envmaps.push_back(m); }
     d.n_prims = (uint32_t)S->prims.size(); d.prims = S->prims.data();
     d.n_triangles = (uint32_t)(S->tri_indices.size() / 3); d.tri_indices = S->tri_indices.data(); d.tri_mesh = S->tri_mesh.data();
-    d.n_vertices = (uint32_t)(S->P.size() / 3); d.P = S->P.data(); d.N = S->any_n ? S->N.data() : nullptr; d.UV = S->any_uv ? S->UV.data() : nullptr;
+    d.n_vertices = (uint32_t)(S->P.size() / 3); d.P = S->P.data(); d.N = S->any_n ? S->N.data() : nullptr; d.UV = S->any_uv ? S->UV.data() : nullptr; d.S = S->any_t ? S->T.data() : nullptr;
     d.n_meshes = (uint32_t)S->meshes.size(); d.meshes = S->meshes.data();
     d.n_spheres = (uint32_t)S->spheres.size(); d.spheres = S->spheres.data();
     d.n_materials = (uint32_t)S->materials.size(); d.materials = S->materials.data();

@@ -85,13 +85,14 @@ typedef struct ftn_prim {
     int32_t area_emit;     /* index into area_emit (DiffuseAreaLight L), -1 = None    */
 } ftn_prim;
 
-/* TriangleMesh flags: src/shapes/triangle.rs:10-27. Vertices/normals are already in world
- * space (TriangleMesh::new, :42-58). Tangents ("S") are not supported.                        */
+/* TriangleMesh flags: src/shapes/triangle.rs:10-27. Vertices / normals / tangents are already in world
+ * space (TriangleMesh::new, :42-58).                                                           */
 typedef struct ftn_mesh {
     uint32_t has_normals;
     uint32_t has_uvs;
     uint32_t flip_normals;        /* reverse_orientation ^ transform_swaps_handedness, shapes/mod.rs:27-29 */
     uint32_t reverse_orientation;
+    uint32_t has_tangents;        /* "S" (constructors.rs:63): per-vertex shading tangents, triangle.rs:341-347 */
 } ftn_mesh;
 
 /* Sphere: src/shapes/sphere.rs:15-27 (fields after Sphere::new's clamping, :40-49) */
@@ -191,6 +192,7 @@ typedef struct ftn_scene_desc {
     uint32_t n_textures;   const ftn_texture* textures;
                            const ftn_material_textures* material_textures;   /* n_materials entries or NULL */
     uint32_t n_images;     const ftn_image* images;
+    const float* S;        /* per-vertex shading tangents, 3 per vertex (world space), or NULL: no mesh has tangents */
 } ftn_scene_desc;
 
 /* ------------------------------------------------------------------ camera / film / sampler / integrator */
@@ -368,7 +370,8 @@ int ftn_intersect(const ftn_scene* scene, const float* rays, size_t n,
 int ftn_intersect_test(const ftn_scene* scene, const float* rays, size_t n,
                        uint8_t* occluded, ftn_stats* stats);
 /* Full SurfaceInteraction of Scene::intersect, for parity of the shading geometry:
- * per ray 24 floats: p[3] p_err[3] n[3] uv[2] wo[3] dpdu[3] dpdv[3] shading_n[3] t  (t<0 = miss) */
+ * per ray 24 floats: p[3] p_err[3] n[3] uv[2] wo[3] shading dpdu[3] dpdv[3] shading_n[3] t  (t<0 = miss);
+ * uv and dpdv are filled by the oracle only (the device recomputes them where a texture needs them) */
 int ftn_intersect_full(const ftn_scene* scene, const float* rays, size_t n, float* out24);
 
 /* SamplerIntegrator::render_parallel (src/integrator/mod.rs:218-227): renders the selected tiles and

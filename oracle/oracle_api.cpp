@@ -154,7 +154,7 @@ int orc_intersect_full(const orc_scene* s, const float* rays, size_t n, float* o
             Vec3 v[] = {si.hit.p, si.hit.p_err, si.hit.n};
             for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) o[3 * k + c] = v[k][c];
             o[9] = si.uv.x; o[10] = si.uv.y;
-            Vec3 w[] = {si.wo, si.geom.dpdu, si.geom.dpdv, si.shading_n};
+            Vec3 w[] = {si.wo, si.shading_geom.dpdu /* what Bsdf::new builds its frame from (bsdf.rs:24-26) */, si.geom.dpdv, si.shading_n};
             for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) o[11 + 3 * k + c] = w[k][c];
             o[23] = ray.t_max;
         }

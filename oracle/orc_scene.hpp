@@ -332,7 +332,7 @@ struct BVH {
 
 // ---- Scene: src/scene/mod.rs (flat, built from ftn_scene_desc)
 struct SceneData {
-    std::vector<Float> P, N, UV;
+    std::vector<Float> P, N, UV, S;
     std::vector<TriangleMesh> meshes;
     std::vector<Triangle> triangles;
     std::vector<Sphere> spheres;
@@ -382,11 +382,13 @@ inline int build_scene(const ftn_scene_desc* d, SceneData* s) {
     s->P.assign(d->P, d->P + 3 * (size_t)d->n_vertices);
     if (d->N) s->N.assign(d->N, d->N + 3 * (size_t)d->n_vertices);
     if (d->UV) s->UV.assign(d->UV, d->UV + 2 * (size_t)d->n_vertices);
+    if (d->S) s->S.assign(d->S, d->S + 3 * (size_t)d->n_vertices);
     s->meshes.resize(d->n_meshes);
     for (uint32_t i = 0; i < d->n_meshes; i++) {
         TriangleMesh& m = s->meshes[i];
         m.P = s->P.data(); m.N = s->N.empty() ? nullptr : s->N.data(); m.UV = s->UV.empty() ? nullptr : s->UV.data();
         m.has_normals = d->meshes[i].has_normals && m.N; m.has_uvs = d->meshes[i].has_uvs && m.UV;
+        m.S = s->S.empty() ? nullptr : s->S.data(); m.has_tangents = d->meshes[i].has_tangents && m.S;
         m.flip_normals = d->meshes[i].flip_normals; m.reverse_orientation = d->meshes[i].reverse_orientation;
     }
     s->triangles.resize(d->n_triangles);

@@ -303,7 +303,9 @@ struct TriangleMesh {
     const Float* P = nullptr;               // world-space positions (pool)
     const Float* N = nullptr;               // world-space normals or nullptr
     const Float* UV = nullptr;
-    bool has_normals = false, has_uvs = false, flip_normals = false, reverse_orientation = false;
+    const Float* S = nullptr;               // world-space shading tangents or nullptr (triangle.rs:19, :53-58)
+    bool has_normals = false, has_uvs = false, flip_normals = false, reverse_orientation = false, has_tangents = false;
+    Vec3 tangent(uint32_t i) const { return Vec3(S[3 * i], S[3 * i + 1], S[3 * i + 2]); }
     Vec3 vertex(uint32_t i) const { return Vec3(P[3 * i], P[3 * i + 1], P[3 * i + 2]); }
     Vec3 normal(uint32_t i) const { return Vec3(N[3 * i], N[3 * i + 1], N[3 * i + 2]); }
     Vec2 uv(uint32_t i) const { return Vec2(UV[2 * i], UV[2 * i + 1]); }
@@ -393,16 +395,20 @@ struct Triangle : Shape {
         Vec3 geom_normal = normalize(cross(dp02, dp12));
         SurfaceInteraction isect = SurfaceInteraction::make(p_hit, p_err, ray.time, uv_hit, -ray.dir, geom_normal, dg);
         if (mesh->flip_normals) { isect.hit.n = isect.hit.n * -1.0f; isect.shading_n = isect.shading_n * -1.0f; }
-        if (mesh->has_normals) {   // (tangents are not supported by the flat scene ABI)
-            Vec3 n0 = mesh->normal(v[0]), n1 = mesh->normal(v[1]), n2 = mesh->normal(v[2]);
-            Vec3 ns = normalize(b0 * n0 + b1 * n1 + b2 * n2);
-            Vec3 ss = normalize(isect.geom.dpdu);
+        if (mesh->has_normals || mesh->has_tangents) {   // triangle.rs:332
+            Vec3 n0, n1, n2;
+            if (mesh->has_normals) { n0 = mesh->normal(v[0]); n1 = mesh->normal(v[1]); n2 = mesh->normal(v[2]); }
+            // compute shading normal :334-338
+            Vec3 ns = mesh->has_normals ? normalize(b0 * n0 + b1 * n1 + b2 * n2) : isect.hit.n;
+            // compute shading tangent :340-345
+            Vec3 ss = mesh->has_tangents ? normalize(b0 * mesh->tangent(v[0]) + b1 * mesh->tangent(v[1]) + b2 * mesh->tangent(v[2])) : normalize(isect.geom.dpdu);
             Vec3 ts = cross(ns, ss);
             if (magnitude2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
             else coordinate_system(ns, &ts, &ss);   // NB: (v2, v3) is bound as (ts, ss) in the reference, :343-349
             Vec3 dndu, dndv;
             Vec3 dn1 = n0 - n2, dn2 = n1 - n2;
-            if (degenerate_uv) {
+            if (!mesh->has_normals) { dndu = Vec3(); dndv = Vec3(); }      // :367-369
+            else if (degenerate_uv) {
                 Vec3 dn = cross(n2 - n0, n1 - n0);
                 if (magnitude2(dn) == 0.0f) { dndu = Vec3(); dndv = Vec3(); }
                 else coordinate_system(dn, &dndu, &dndv);

@@ -579,13 +579,13 @@ def test_furnace_path_no_rr_on_the_wavefront_pipeline(gpu, orc_det):
     sampler stream.  With max_depth 10 the estimator's mean is 2 - 2^-10 (the series 1 + 1/2 + 1/4 + ... is cut after ten scattering
     terms), which sits 2.3e-5 inside the reference's +-0.001 window around 2.0 -- the reference's assertion holds for its own stream at
     128 spp but is no statement about another stream's Monte-Carlo noise.  So: 1024 spp (noise ~3e-5 per pixel), every pixel within
-    +-0.001 of the true mean 2 - 2^-10 and the image mean within 1e-4 of it; bit-exact against the oracle; every path takes all 11 segments."""
+    +-0.001 of the true mean 2 - 2^-10 and the image mean within 1e-4 of it; bit-exact against the oracle; every path takes all 11 segments (plus the MIS rays of its direct-lighting estimates)."""
     integ, smp = PathIntegrator.new(10, 0.0), RandomSampler(1024, 0, indexed=True)
     (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, scenes.furnace, integ, smp, WAVE)
     mean = 2.0 - 2.0 ** -10
     assert np.abs(rgb - mean).max() <= 0.001, float(np.abs(rgb - mean).max())
     assert abs(float(rgb.mean()) - mean) <= 1e-4 and np.abs(rgb - 2.0).max() <= 0.002
     assert_film_equal(px, pxo, st["spill_samples"], "furnace path_no_rr, wavefront")
-    assert st["rays_closest"] == sto["rays_closest"] == 16 * 16 * 1024 * 11 and st["rays_any"] == sto["rays_any"]
+    assert st["rays_closest"] == sto["rays_closest"] >= 16 * 16 * 1024 * 11 and st["rays_any"] == sto["rays_any"]
     prod = scenes.render(gpu, *scenes.furnace(gpu), integ, smp, backend_kwargs=dict(pipeline=WAVE))     # production kernels (no counting build)
     assert np.array_equal(bits(prod[1]), bits(px))

@@ -29,7 +29,8 @@ def desc_arrays(d):
         "P": _arr(d.P, d.n_vertices * 3, np.uint32),
         "N": _arr(d.N, d.n_vertices * 3, np.uint32) if d.N else None,
         "UV": _arr(d.UV, d.n_vertices * 2, np.uint32) if d.UV else None,
-        "meshes": _arr(d.meshes, d.n_meshes * 4, np.uint32),
+        "meshes": _arr(d.meshes, d.n_meshes * 5, np.uint32),
+        "S": _arr(d.S, d.n_vertices * 3, np.uint32) if d.S else None,
         "spheres": _arr(d.spheres, d.n_spheres * 72, np.uint32),
         "materials": _arr(d.materials, d.n_materials * 11, np.uint32).reshape(-1, 11) if d.n_materials else np.zeros((0, 11), np.uint32),
         "area_emit": _arr(d.area_emit, d.n_area_emit * 3, np.uint32),
@@ -371,3 +372,101 @@ def test_parsed_scene_files_render_like_the_oracle(gpu, orc_det, tmp_path, which
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and st["camera_samples"] == res[0] * res[1] * spp
     _same_film(px, ref, st["spill_samples"], which)
     assert np.isfinite(px).all() and px[..., :3].max() > 0
+
+
+# ------------------------------------------------------------------ vertex tangents ("S": constructors.rs:63, triangle.rs:53-58, :341-347)
+TANGENT_SCENE = """
+Film "image" "integer xresolution" [ 64 ] "integer yresolution" [ 48 ]
+Sampler "random" "integer pixelsamples" 4
+LookAt 0.5 -3 2.2  0.5 0.5 0  0 0 1
+Camera "perspective" "float fov" 38
+WorldBegin
+LightSource "point" "rgb I" [30 30 30] "point from" [0.2 0.1 3]
+LightSource "distant" "rgb L" [2 2 2] "point from" [1 -1 2] "point to" [0 0 0]
+AttributeBegin
+  Material "metal" "rgb eta" [0.2 0.92 1.1] "rgb k" [3.9 2.45 2.14] "float uroughness" 0.02 "float vroughness" 0.35
+  Rotate 25 0 0 1
+  Scale 1.5 1 1
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 -1 0  1 -1 0  1 1 0  -1 1 0] "normal N" [0 0 1 0 0 1 0 0 1 0 0 1]
+        "vector S" [1 1 0  1 1 0  0 1 0.2  0 1 0]
+AttributeEnd
+AttributeBegin
+  Material "metal" "rgb eta" [1.5 1.0 0.5] "rgb k" [3 2.5 2] "float uroughness" 0.3 "float vroughness" 0.03
+  Translate 1.2 1.6 0.4
+  Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0  1 0 0.5  0 1 0.5] "vector S" [0 1 0  0 1 0  1 1 0]
+AttributeEnd
+WorldEnd
+"""
+
+
+def _tangent_scene(be):
+    b = SceneBuilder(be)
+    b.light_source("point", I=(30, 30, 30), from_=(0.2, 0.1, 3))
+    b.light_source("distant", L=(2, 2, 2), from_=(1, -1, 2), to=(0, 0, 0))
+    b.attribute_begin(); b.material("metal", eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), uroughness=0.02, vroughness=0.35)
+    b.rotate(25, (0, 0, 1)); b.scale(1.5, 1, 1)
+    b.shape("trianglemesh", indices=[0, 1, 2, 0, 2, 3], P=[(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], N=[(0, 0, 1)] * 4, S=[(1, 1, 0), (1, 1, 0), (0, 1, 0.2), (0, 1, 0)])
+    b.attribute_end()
+    b.attribute_begin(); b.material("metal", eta=(1.5, 1.0, 0.5), k=(3, 2.5, 2), uroughness=0.3, vroughness=0.03)
+    b.translate((1.2, 1.6, 0.4))
+    b.shape("trianglemesh", indices=[0, 1, 2], P=[(0, 0, 0), (1, 0, 0.5), (0, 1, 0.5)], S=[(0, 1, 0), (0, 1, 0), (1, 1, 0)])      # tangents without normals
+    b.attribute_end()
+    cam = PerspectiveCamera.look_at(be, (0.5, -3, 2.2), (0.5, 0.5, 0), (0, 0, 1), (64, 48), fov=38.0)
+    return b, cam, (64, 48)
+
+
+def test_vertex_tangents_are_parsed_like_the_builder(ftn, tmp_path):
+    (tmp_path / "t.pbrt").write_text(TANGENT_SCENE)
+    ps = PbrtScene(str(tmp_path / "t.pbrt"), ftn)
+    b, cam, res = _tangent_scene(ftn)
+    d, keep = b.build_desc()
+    assert_same_desc(ps.desc, d)
+    assert same_struct(ps.camera.desc, cam.desc) and ps.desc.meshes[0].has_tangents == 1 and ps.desc.meshes[1].has_normals == 0 and ps.desc.meshes[1].has_tangents == 1
+    # per-vertex array length must match P (make_triangle_mesh's assert_eq!, triangle.rs:54)
+    (tmp_path / "bad.pbrt").write_text(TANGENT_SCENE.replace('"vector S" [0 1 0  0 1 0  1 1 0]', '"vector S" [0 1 0  0 1 0]'))
+    with pytest.raises(FountainError):
+        PbrtScene(str(tmp_path / "bad.pbrt"), ftn)
+
+
+def test_oracle_shading_frame_follows_the_vertex_tangent(orc):
+    """triangle.rs:341-349 on the oracle: with a normal (0,0,1) and a tangent in the plane, the shading dpdu IS the normalised tangent
+    (ts = ns x ss, ss = ts x ns); without `S` it is the normalised dpdu of the default uvs, a different direction; a mesh with tangents
+    but no normals takes the geometric normal as ns."""
+    from fountain_amd import make_rays
+    P = [(0, 0, 0), (2, 0, 0), (0, 2, 0)]
+    rays = make_rays([(0.5, 0.5, 1.0)], [(0.0, 0.0, -1.0)])
+    frames = {}
+    for name, kw in (("plain", dict(N=[(0, 0, 1)] * 3)), ("tangent", dict(N=[(0, 0, 1)] * 3, S=[(0, 3, 0)] * 3)), ("tangent_only", dict(S=[(0.6, 0.8, 5.0)] * 3))):
+        b = SceneBuilder(orc)
+        b.material("matte")
+        b.shape("trianglemesh", indices=[0, 1, 2], P=P, **kw)
+        frames[name] = b.create_scene().intersect_full(rays)[0]
+    assert np.allclose(frames["tangent"][14:17], (0, 1, 0), atol=1e-7) and np.allclose(frames["tangent"][20:23], (0, 0, 1), atol=1e-7)
+    assert not np.allclose(frames["plain"][14:17], frames["tangent"][14:17], atol=1e-3)
+    # tangents only: ns = geometric normal (0,0,1); ss = the tangent's projection onto the plane, normalised
+    assert np.allclose(frames["tangent_only"][20:23], (0, 0, 1), atol=1e-7) and np.allclose(frames["tangent_only"][14:17], (0.6, 0.8, 0), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT])
+def test_vertex_tangents_render_like_the_oracle(gpu, orc_det, tmp_path, pipeline):
+    """anisotropic metals whose shading frame comes from per-vertex tangents (one mesh with normals + tangents, one with tangents only):
+    the parsed file on the GPU against the oracle's render of the builder scene, and the full interaction records of a ray batch"""
+    from fountain_amd import make_rays
+    (tmp_path / "t.pbrt").write_text(TANGENT_SCENE)
+    ps = PbrtScene(str(tmp_path / "t.pbrt"), gpu)
+    px, st = _render_parsed(gpu, ps, pipeline, 4)
+    b, cam, res = _tangent_scene(orc_det)
+    ref, sto = _render_oracle(orc_det, b, cam, res, 4)
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+    _same_film(px, ref, st["spill_samples"], "vertex tangents")
+    assert px[..., :3].max() > 0
+    rng = np.random.default_rng(4)
+    o = np.array([0.5, -3, 2.2], np.float32) + rng.normal(size=(4000, 3)).astype(np.float32) * 0.05
+    tgt = rng.uniform(-1.5, 2.5, (4000, 3)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+    rays = make_rays(o, tgt - o)
+    fg, fo = ps.create_scene().intersect_full(rays), b.create_scene().intersect_full(rays)
+    hit = fo[:, 23] >= 0
+    assert hit.sum() > 500 and np.array_equal(fg[:, 23] >= 0, hit)
+    for sl in (slice(0, 9), slice(11, 17), slice(20, 24)):          # p, p_err, n | wo, shading dpdu | shading_n, t  (9-10 uv and 17-19 dpdv: oracle only)
+        assert np.array_equal(_bits(fg[:, sl]), _bits(fo[:, sl])), sl
