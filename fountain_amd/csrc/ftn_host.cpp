@@ -474,7 +474,10 @@ static int validate_desc(const ftn_scene_desc* d) {
     }
     for (uint32_t i = 0; i < d->n_envmaps; i++) {
         uint32_t w = d->envmaps[i].width, h = d->envmaps[i].height;
-        if (w != h || w == 0 || (w & (w - 1))) return fail(FTN_ERR_UNSUPPORTED, "environment maps must be square with a power-of-two side");
+        /* any size: compute_distribution's filter width 1 / max(w, h) puts the lookup at pyramid level floor(log2 max) - log2 max, which is
+         * 0 for a power of two (lerp with weight exactly 0 on level 1) and negative otherwise (level 0 alone, mipmap.rs:247-249) -- level 1
+         * never contributes, so no pyramid is needed for environment maps (infinite.rs:63-77) */
+        if (w == 0 || h == 0) return fail(FTN_ERR_INVALID_ARGUMENT, "environment map without texels");
     }
     for (uint32_t i = 0; i < d->n_lights; i++) {
         if (d->lights[i].type > FTN_LIGHT_INFINITE) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown light type");
@@ -769,7 +772,8 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             const ftn_envmap& e = d->envmaps[src.envmap];
             memcpy(L.l2w, src.light_to_world.m, 64); memcpy(L.w2l, src.light_to_world.inv, 64);
             L.env_w = e.width; L.env_h = e.height;
-            /* compute_distribution infinite.rs:63-78: (height, width) = resolution() name swap, square maps only; level = 0 exactly */
+            /* compute_distribution infinite.rs:63-78: (height, width) = resolution() name swap (the distribution of a w x h map has h columns and
+             * w rows, its rows filled from texture rows as if the map were h wide: reproduced as written); only pyramid level 0 is ever read */
             const uint32_t height = e.width, width = e.height;
             std::vector<float4> tex4((size_t)e.width * e.height);
             for (size_t k = 0; k < tex4.size(); k++) tex4[k] = make_float4(e.texels[3 * k], e.texels[3 * k + 1], e.texels[3 * k + 2], 0.0f);

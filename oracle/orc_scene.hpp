@@ -105,7 +105,7 @@ struct Light {
     Spectrum area_emitted_radiance(const SurfaceHit& hit, Vec3 w) const {   // diffuse.rs:44-50
         return dot(hit.n, w) > 0.0f ? emit : Spectrum(0.0f);
     }
-    // compute_distribution: infinite.rs:63-78  (NB (height,width) = resolution() name swap; square maps only)
+    // compute_distribution: infinite.rs:63-78  (NB (height,width) = resolution() name swap: a w x h map gives a distribution with h columns, w rows)
     void compute_distribution() {
         int height = l_map->w, width = l_map->h;
         std::vector<Float> img((size_t)width * height);
@@ -114,7 +114,8 @@ struct Light {
             Float sin_theta = m_sin(PI * ((Float)j + 0.5f) / (Float)height);
             for (int i = 0; i < width; i++) {
                 Float uu = (Float)i / (Float)width;
-                // filter = 1/max(w,h) -> level exactly 0 for power-of-two maps -> lerp(0, tri(0), tri(1)) = tri(0)*1 + tri(1)*0;
+                // filter = 1/max(w,h) -> level = floor(log2 max) - log2 max: exactly 0 for a power of two -> lerp(0, tri(0), tri(1)) = tri(0)*1 + tri(1)*0,
+                // negative otherwise -> triangle(0) alone (mipmap.rs:247-249): pyramid level 1 never contributes;
                 // a 1x1 map takes the `level >= levels-1` branch = texel(0,0,0)
                 Spectrum tex = (l_map->w == 1 && l_map->h == 1) ? l_map->texel(0, 0) : l_map->triangle(Vec2(uu, vv));
                 img[i + (size_t)j * width] = tex.luminance() * sin_theta;
@@ -410,7 +411,7 @@ inline int build_scene(const ftn_scene_desc* d, SceneData* s) {
     s->envmaps.resize(d->n_envmaps);
     for (uint32_t i = 0; i < d->n_envmaps; i++) {
         EnvMap& e = s->envmaps[i]; e.w = (int)d->envmaps[i].width; e.h = (int)d->envmaps[i].height;
-        if (e.w != e.h || e.w <= 0 || (e.w & (e.w - 1))) return FTN_ERR_UNSUPPORTED;
+        if (e.w <= 0 || e.h <= 0) return FTN_ERR_INVALID_ARGUMENT;
         e.texels.assign(d->envmaps[i].texels, d->envmaps[i].texels + (size_t)e.w * e.h * 3);
     }
     std::vector<Primitive> prims(d->n_prims);

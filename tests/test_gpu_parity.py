@@ -589,3 +589,17 @@ def test_furnace_path_no_rr_on_the_wavefront_pipeline(gpu, orc_det):
     assert st["rays_closest"] == sto["rays_closest"] >= 16 * 16 * 1024 * 11 and st["rays_any"] == sto["rays_any"]
     prod = scenes.render(gpu, *scenes.furnace(gpu), integ, smp, backend_kwargs=dict(pipeline=WAVE))     # production kernels (no counting build)
     assert np.array_equal(bits(prod[1]), bits(px))
+
+
+@pytest.mark.parametrize("pipeline", [MEGA, WAVE])
+@pytest.mark.parametrize("shape", [(6, 3), (3, 6), (8, 4), (5, 7), (1, 4), (12, 1), (100, 37)])
+def test_environment_maps_of_any_size(gpu, orc_det, shape, pipeline):
+    """non-square and non-power-of-two environment maps (infinite.rs:63-77: only pyramid level 0 is ever read; the (height, width) name
+    swap of compute_distribution reproduced as written): importance sampling, pdf and Le bit-equal to the oracle's"""
+    from test_oracle_integration import _env_scene
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    tex = (rng.random(shape + (3,)) ** 3 * 2).astype(np.float32)
+    tex[shape[0] // 2, shape[1] // 3] = 30.0
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, lambda be: _env_scene(be, tex), PathIntegrator.new(4, 1.0), RandomSampler(4, 0, indexed=True), pipeline)
+    assert_film_equal(px, pxo, st["spill_samples"], "env map %dx%d" % shape)
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and rgb.max() > 0.5

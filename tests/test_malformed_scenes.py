@@ -51,7 +51,7 @@ MUTATIONS = {
     "mesh id": lambda d: d.tri_mesh.__setitem__(0, 5),
     "light type": lambda d: setattr(d.lights[0], "type", 8),
     "envmap index": lambda d: setattr(d.lights[0], "envmap", 4),
-    "envmap not a power of two": lambda d: setattr(d.envmaps[0], "width", 3),
+    "envmap without texels": lambda d: setattr(d.envmaps[0], "width", 0),
     "checkerboard child": lambda d: setattr(d.textures[2], "tex1", 40),
     "texture kind": lambda d: setattr(d.textures[0], "kind", 17),
     "image index": lambda d: setattr(d.textures[3], "image", 2),

@@ -165,3 +165,39 @@ def test_tile_shards_sum_to_the_whole(orc_det):
     for r in range(3):
         si.render_parallel(sc, film, smp, tiles=(r, 3, 0))
     assert np.array_equal(film.pixels.view(np.uint32), whole.view(np.uint32))
+
+
+# ------------------------------------------------------------------ environment maps of any size (infinite.rs:63-77)
+def _env_scene(be, tex, res=(40, 32)):
+    from fountain_amd import PerspectiveCamera, SceneBuilder, scenes
+    b = SceneBuilder(be)
+    b.attribute_begin(); b.rotate(20.0, (0.2, 0.1, 1.0)); b.light_source("infinite", texels=tex); b.attribute_end()
+    b.material("matte", Kd=(0.6, 0.6, 0.6))
+    scenes._quad(b, (-4, -4, 0), (4, -4, 0), (4, 4, 0), (-4, 4, 0))
+    b.attribute_begin(); b.material("metal", eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), roughness=0.1); b.translate((0, 0, 0.8)); b.shape("sphere", radius=0.8); b.attribute_end()
+    cam = PerspectiveCamera.look_at(be, (0, -6, 3), (0, 0, 0.5), (0, 0, 1), res, fov=40.0)
+    return b, cam, res
+
+
+ENV_SHAPES = [(6, 3), (3, 6), (8, 4), (5, 7), (1, 4), (12, 1)]      # (height, width) of the texel array: non-square, non-power-of-two
+
+
+@pytest.mark.parametrize("shape", ENV_SHAPES)
+def test_oracle_renders_with_environment_maps_of_any_size(orc, shape):
+    """InfiniteAreaLight::compute_distribution reads pyramid level 0 only whatever the map's size (its filter width 1 / max(w, h) gives
+    level floor(log2 max) - log2 max <= 0, and exactly 0 -- weight 0 on level 1 -- for a power of two), so maps need not be square or a
+    power of two.  Energy check: under a CONSTANT map of any shape the matte ground far from the sphere receives the same radiance as
+    under the 1 x 1 map of new_uniform (the importance distribution only changes the noise, not the mean)."""
+    from fountain_amd import PathIntegrator, RandomSampler, scenes
+    h, w = shape
+    const = np.full((h, w, 3), 0.8, np.float32)
+    rgb_c, _, st_c, _ = scenes.render(orc, *_env_scene(orc, const), PathIntegrator(3, 1.0), RandomSampler(64, 0, indexed=True))
+    rgb_1, _, st_1, _ = scenes.render(orc, *_env_scene(orc, np.full((1, 1, 3), 0.8, np.float32)), PathIntegrator(3, 1.0), RandomSampler(64, 0, indexed=True))
+    assert np.isfinite(rgb_c).all() and st_c["camera_samples"] == 40 * 32 * 64
+    assert abs(float(rgb_c[24:, :8].mean()) / float(rgb_1[24:, :8].mean()) - 1.0) < 0.05
+    # a map with one bright texel: finite, non-negative, brighter than the constant one somewhere
+    rng = np.random.default_rng(h * 16 + w)
+    tex = (rng.random((h, w, 3)) ** 3).astype(np.float32)
+    tex[h // 2, w // 3] = 25.0
+    rgb, _, st, _ = scenes.render(orc, *_env_scene(orc, tex), PathIntegrator(3, 1.0), RandomSampler(16, 0, indexed=True))
+    assert np.isfinite(rgb).all() and (rgb >= 0).all() and rgb.max() > 1.0
