@@ -138,7 +138,7 @@ typedef struct ftn_light {
 } ftn_light;
 
 /* Level 0 of the MIPMap<Spectrum> behind InfiniteAreaLight (src/mipmap.rs:245-312, ImageWrap::Repeat):
- * texels[(t*width + s)*3 + c]. Must be square with power-of-two side (resize row). */
+ * texels[(t*width + s)*3 + c]. Any size: the light only ever reads level 0 (infinite.rs:63-77). */
 typedef struct ftn_envmap {
     uint32_t width, height;
     const float* texels;
