@@ -728,6 +728,14 @@ __global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, cons
     keys[i] = (m << 3) | oct;
 }
 
+/* experiment (FTN_WF_SORT_HIT=1): order the active queue by the primitive each path just hit -- BVH order is spatial
+ * order -- so that shading, and the shadow / MIS / continuation rays it emits, run in spatial order */
+__global__ void __launch_bounds__(256) k_wf_hit_keys(WfBuffers W, const uint32_t* __restrict__ queue, uint32_t count, uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    keys[i] = (uint32_t)(W.hit_prim[queue[i]] + 1);            /* a miss (-1) sorts first */
+}
+
 struct WavefrontState {
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     size_t cap_paths = 0;
@@ -1010,6 +1018,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const uint32_t overlap_mode = knob("FTN_WF_OVERLAP", 2);
     const bool drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
     const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
+    const bool sort_hit = knob("FTN_WF_SORT_HIT", 0) != 0;
+    uint32_t n_active = 0;                 /* length of the active queue the next classify reads (known from the previous bounce's poll) */
     int ev_used = 0;
     struct Span { int a, b, kind; };
     std::vector<Span> spans;
@@ -1084,7 +1094,20 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
                 hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
+                uint32_t* const q_in = W.q_active[in_q];
+                if (sort_hit && it > 0 && n_active >= 16384u && !beside) {      /* experiment: active queue in hit-primitive order (scratch: the exception queues, idle between traces) */
+                    uint32_t* k_in = W.q_exc_closest, *k_out = W.q_exc_closest + st->cap_paths, *v_out = W.q_exc_any;
+                    hipLaunchKernelGGL(k_wf_hit_keys, dim3((n_active + 255) / 256), dim3(256), 0, stream, W, q_in, n_active, k_in);
+                    int end_bit = 1; while ((1ull << end_bit) <= (unsigned long long)P.S.n_prims) end_bit++;
+                    size_t need = 0;
+                    hipcub::DoubleBuffer<uint32_t> keys(k_in, k_out), vals(q_in, v_out);
+                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, vals, (int)n_active, 0, end_bit, stream));
+                    if (need > st->sort_tmp_bytes) { if (st->sort_tmp) (void)hipFree(st->sort_tmp); st->sort_tmp = nullptr; st->sort_tmp_bytes = 0; WF_TRY(hipMalloc(&st->sort_tmp, need)); st->sort_tmp_bytes = need; }
+                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, keys, vals, (int)n_active, 0, end_bit, stream));
+                    W.q_active[in_q] = vals.Current();
+                }
                 hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
+                W.q_active[in_q] = q_in;
             }
             if (beside) WF_TRY(hipStreamWaitEvent(stream, st->ev_side, 0));     /* shading needs the occlusion results (classify above did not) */
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
@@ -1134,7 +1157,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                     WF_TRY(hipStreamSynchronize(stream));
                 }
                 if (it >= P.max_depth && count && knob("FTN_WF_DEBUG", 0)) fprintf(stderr, "[wf] wave steps so far: node %u leaf %u; lanes during node steps (x64): idle %u waiting-with-leaf %u\n", st->host_counters[CTR(6)], st->host_counters[CTR(7)], st->host_counters[CTR(8)], st->host_counters[CTR(9)]);
-                if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
+                n_active = st->host_counters[CTR(in_q == 0 ? 0 : 1)];
+                if (n_active == 0) break;
             }
         }
         if (W.mis_any) mis_any_rays += st->host_counters[CTR(10)];   /* the last poll of the pass saw the pass's total */
