@@ -960,7 +960,7 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
     W.n_paths = n; W.ray = ray; W.sh = ray; W.hit = hit; W.hit_prim = hit_prim; W.occluded = occluded; W.counters = counters; W.q_exc_closest = q_exc; W.q_exc_any = q_exc;
     RenderParams P; memset(&P, 0, sizeof(P)); P.S = S; P.stats = stats;
     const uint32_t* q = queue;
-    if (knob("FTN_WF_SORT", 1)) { rc = sort_ray_queue(st, P, W, any, queue, n, scratch, scratch + n, scratch + 2 * (size_t)n, 7, stream, &q); if (rc) { cleanup(); return rc; } }
+    if (knob("FTN_WF_SORT", 0)) { rc = sort_ray_queue(st, P, W, any, queue, n, scratch, scratch + n, scratch + 2 * (size_t)n, 7, stream, &q); if (rc) { cleanup(); return rc; } }
     const size_t lds = (size_t)stack_entries * 256 * sizeof(uint32_t);
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned grid = std::min<unsigned>((unsigned)st->n_cu * per_cu, (n + 255) / 256);
@@ -1017,7 +1017,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
      * paths: short launches are mostly drain and gain 4 %, at 128 Mi paths the gain is 0.7 % and not worth the second stream */
     const uint32_t overlap_mode = knob("FTN_WF_OVERLAP", 2);
     const bool drain_gate = knob("FTN_WF_DRAIN_GATE", 1) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
-    const uint32_t sort_bits = knob("FTN_WF_SORT", 1) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
+    /* Coherence sort of the secondary closest-hit queue (FTN_WF_SORT=1): with the two-record kernels of round 1 it paid 6 %; the four-box
+     * kernels are instruction-issue bound and gain as much as the sort (and its per-bounce read-back of the queue lengths) costs: 354.1 vs
+     * 353.4 ms per step on the config-5 scene, and it loses 6 % on the smaller configurations (profiles/r02).  Off by default. */
+    const uint32_t sort_bits = knob("FTN_WF_SORT", 0) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
     const bool sort_hit = knob("FTN_WF_SORT_HIT", 0) != 0;
     uint32_t n_active = 0;                 /* length of the active queue the next classify reads (known from the previous bounce's poll) */
     int ev_used = 0;
