@@ -606,6 +606,239 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
     if (err) atomicCAS(&P.stats->error, 0, err);
 }
 
+/* ------------------------------------------------------------------ DirectLightingIntegrator / WhittedIntegrator through the queues
+ * (direct_lighting.rs:50-110, whitted.rs:20-75, specular_reflect / specular_transmit integrator/mod.rs:39-178)
+ *
+ * Their radiance is a NESTED product: Li(depth d) = local_d + f_d * Li(depth d + 1) * |cos_d| / pdf_d, evaluated innermost first.
+ * A wavefront walks the chain forwards, so every depth keeps its terms -- dlA[d] = {local_d.rgb, pdf_d}, dlB[d] = {f_d.rgb, |cos_d|},
+ * level-major SoA -- and the path is folded from its deepest level when it ends (dl_unwind: the same expressions, in the same order,
+ * as the megakernel's direct_li and as the recursion they restate).  Only chains are supported, as in the megakernel: a BSDF with
+ * both specular lobes (specular glass) reports FTN_ERR_UNSUPPORTED like the reference's todo!(); so does a primitive without material
+ * (unimplemented!() at direct_lighting.rs:103) and a chain longer than WF_DL_MAX levels.
+ * Per level: `local` = emitted radiance (direct lighting only) + the direct term.  DirectLightingIntegrator: uniform_sample_one_light,
+ * the same deferred shadow / MIS rays as the path integrator (resolved when the path comes back after the traces), but called for every
+ * BSDF (no "has non-specular lobes" test) and not weighted by a throughput.  WhittedIntegrator: every light once, one 2D sample and one
+ * shadow ray each (ray l of path p in slot p + l * n_paths), up to WF_WH_MAX_LIGHTS lights; no MIS ray, no emitted term.
+ * The 2D sample of specular_transmit is drawn after the reflect recursion returns and never used by a supported material: with one
+ * stream per camera sample (the indexed sampler, the only one the wavefront runs) skipping it changes nothing. */
+#define WF_DL_MAX 8u
+#define WF_WH_MAX_LIGHTS 4u
+__device__ inline void dl_unwind(const RenderParams& P, const WfBuffers& W, uint32_t p, uint32_t depth, bool have_tail, Rgb tail) {
+    Rgb li = have_tail ? tail : Rgb(0.0f);
+    bool child = have_tail;
+    for (int d = (int)depth - 1; d >= 0; d--) {
+        const float4 a = W.dlA[(size_t)d * W.n_paths + p];
+        Rgb r(a.x, a.y, a.z);
+        if (child) { const float4 b = W.dlB[(size_t)d * W.n_paths + p]; r = r + Rgb(b.x, b.y, b.z) * li * b.w / a.w; }
+        else if ((uint32_t)d + 1 < P.max_depth) r = r + Rgb(0.0f);                   /* radiance += specular_reflect (= 0) */
+        if ((uint32_t)d + 1 < P.max_depth) r = r + Rgb(0.0f);                        /* radiance += specular_transmit (= 0) */
+        li = r; child = true;
+    }
+    W.rad[p] = make_float4(li.r, li.g, li.b, 0.0f);
+}
+
+template <bool WHITTED>
+__global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W, int in_q) {
+    const DScene& S = P.S;
+    uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
+    cbase[0] = 0;
+#pragma unroll
+    for (int k = 0; k < WF_NCLASS; k++) { ccnt[k] = W.cls[CTR(k)]; cbase[k + 1] = cbase[k] + ((ccnt[k] + 255u) & ~255u); }
+    const uint32_t count = cbase[WF_NCLASS];
+    uint32_t* out_q = W.q_active[in_q ^ 1];
+    uint32_t* out_count = &W.counters[CTR(in_q == 0 ? 1 : 0)];
+    int err = 0;
+    const uint32_t stride = gridDim.x * 256u;
+    const uint32_t rounds = (count + stride - 1) / stride;
+    const uint32_t nl = S.n_lights;
+    for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t qi = round * stride + blockIdx.x * 256u + threadIdx.x;
+        bool have = false; uint32_t sorted_idx = 0;
+        if (qi < count) {
+            uint32_t c = 0, cb = 0, cc = ccnt[0];
+#pragma unroll
+            for (int k = 1; k < WF_NCLASS; k++) if (qi >= cbase[k]) { c = (uint32_t)k; cb = cbase[k]; cc = ccnt[k]; }
+            have = qi - cb < cc;
+            sorted_idx = c * W.seg_cap + (qi - cb);
+        }
+        bool push_active = false, push_closest = false, push_mis = false, push_mis_any = false;
+        uint32_t sh_mask = 0;                                    /* shadow rays this path emits: bit l = the ray in slot p + l * n_paths (Whitted: one per light) */
+        uint32_t p = 0;
+        if (have) {
+            p = W.q_sorted[sorted_idx];
+            const float4 bq = W.beta[p], lq = W.rad[p];
+            uint32_t ps = __float_as_uint(bq.w);
+            uint32_t depth = ps & PS_BOUNCE_MASK;                 /* levels stored so far = index of the level shaded now */
+            /* ---- finish the direct term of level depth - 1 (its rays have been traced) */
+            if (ps & PS_DIRECT) {
+                const uint32_t lv = depth - 1u;
+                float4 a = W.dlA[(size_t)lv * W.n_paths + p];
+                Rgb rad(a.x, a.y, a.z);
+                if (WHITTED) {                                   /* whitted.rs:42-58: radiance += f * Li * |cos| / pdf for every unoccluded light, in light order */
+                    const uint32_t mask = __float_as_uint(lq.w);
+                    for (uint32_t l = 0; l < nl; l++) if ((mask >> l) & 1u) {
+                        const float4 t = W.whT[(size_t)l * W.n_paths + p];
+                        if (!W.occluded[p + (size_t)l * W.n_paths]) rad = rad + Rgb(t.x, t.y, t.z);
+                    }
+                } else {                                         /* uniform_sample_one_light = n_lights * estimate_direct (integrator/mod.rs:289-395) */
+                    const float4 q0 = W.pend0[p], q1 = W.pend1[p];
+                    Rgb radiance(0.0f);
+                    if ((ps & PS_SHADOW) && !W.occluded[p]) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
+                    const int light_index = (int)__float_as_uint(lq.w);
+                    const DLight& Lt = S.lights[light_index];
+                    if (ps & PS_MIS_ANY) {
+                        const float4 md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
+                        Rgb inc(0.0f);
+                        if (!W.occluded[p + W.n_paths]) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
+                        if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
+                    } else if (ps & PS_MIS) {
+                        const DHit mh = load_hit(W, p + W.n_paths);
+                        const float4 mo = W.ray[2 * (size_t)(p + W.n_paths)], md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
+                        Rgb inc(0.0f);
+                        if (mh.prim >= 0) {
+                            const uint4 pi = S.prim_info[2 * mh.prim];
+                            if ((int)pi.y >= 0 && (int)pi.y == light_index) {
+                                DRay r0; r0.o = V3(mo.x, mo.y, mo.z); r0.d = V3(md.x, md.y, md.z); r0.t_max = FTN_INF; r0.time = 0.0f;
+                                DSI s2; make_interaction(S, mh, r0, &s2);
+                                inc = area_Le(Lt, s2.hit.n, -r0.d);
+                            }
+                        } else if (Lt.kind == LK_INFINITE) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
+                        if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
+                    }
+                    rad = rad + (float)nl * radiance;
+                }
+                a.x = rad.r; a.y = rad.g; a.z = rad.b;
+                W.dlA[(size_t)lv * W.n_paths + p] = a;
+                ps &= ~(PS_DIRECT | PS_SHADOW | PS_MIS | PS_MIS_ANY);
+            }
+            if (!(ps & PS_ALIVE)) {
+                dl_unwind(P, W, p, depth, false, Rgb(0.0f));       /* the chain ended at its last level: fold it */
+                W.beta[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(ps));
+            } else {
+                const float4 ro = W.ray[2 * (size_t)(p)], rdv = W.ray[2 * (size_t)(p) + 1];
+                DRay ray0; ray0.o = V3(ro.x, ro.y, ro.z); ray0.d = V3(rdv.x, rdv.y, rdv.z); ray0.t_max = rdv.w; ray0.time = 0.0f;
+                const DHit h = load_hit(W, p);
+                bool alive = false; uint32_t light_word = 0; bool ended = false;
+                if (h.prim < 0) { dl_unwind(P, W, p, depth, true, scene_env_Le(S, ray0.d)); ended = true; }      /* None => environment_emitted_radiance */
+                else if (depth >= WF_DL_MAX) { err = FTN_ERR_UNSUPPORTED; ended = true; }
+                else {
+                    DSI si; make_interaction(S, h, ray0, &si);
+                    DBsdf B;
+                    if (si.mat < 0 || !make_bsdf<-1>(S.materials[si.mat], si, false, &B)) { err = FTN_ERR_UNSUPPORTED; ended = true; }
+                    else {
+                        Rng rng; { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
+                        Rgb rad(0.0f);
+                        if (WHITTED) {
+                            uint32_t mask = 0;
+                            if (nl > WF_WH_MAX_LIGHTS) err = FTN_ERR_UNSUPPORTED;
+                            else for (uint32_t l = 0; l < nl; l++) {
+                                const DLight& Lt = S.lights[l];
+                                DLiSample ls = light_sample(S, Lt, si.hit, rng.next2());
+                                if (ls.radiance.is_black() || ls.pdf == 0.0f) continue;
+                                Rgb f = bsdf_f(B, si.wo, ls.wi, T_ALL);
+                                if (!f.is_black()) {
+                                    DRay sr = spawn_ray_to_hit(si.hit, ls.p1);
+                                    const size_t slot = p + (size_t)l * W.n_paths;
+                                    W.sh[2 * slot] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f); W.sh[2 * slot + 1] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.t_max);
+                                    const Rgb term = f * ls.radiance * abs_dot(ls.wi, si.shading_n) / ls.pdf;
+                                    W.whT[slot] = make_float4(term.r, term.g, term.b, 0.0f);
+                                    mask |= 1u << l;
+                                }
+                            }
+                            if (mask) { ps |= PS_DIRECT; light_word = mask; sh_mask = mask; }
+                        } else {
+                            if (si.light >= 0) rad = rad + area_Le(S.lights[si.light], si.hit.n, si.wo);      /* radiance += intersect.emitted_radiance(wo) */
+                            else rad = rad + Rgb(0.0f);
+                            if (nl > 0) {                                     /* uniform_sample_one_light + first half of estimate_direct */
+                                const uint32_t ln = (uint32_t)f2usize(fmin_(rng.next() * (float)nl, (float)(nl - 1)));
+                                const V2 ul = rng.next2(), us = rng.next2();
+                                const DLight& Lt = S.lights[ln];
+                                const uint32_t flags = T_ALL & ~T_SPECULAR;
+                                const bool delta = Lt.kind == LK_POINT || Lt.kind == LK_DISTANT;
+                                ps |= PS_DIRECT; light_word = ln;
+                                Rgb ld(0.0f); float mis_w = 0.0f, mis_pdf = 1.0f; Rgb mis_f(0.0f);
+                                DLiSample ls = light_sample(S, Lt, si.hit, ul);
+                                if (ls.pdf > 0.0f && !ls.radiance.is_black()) {
+                                    Rgb f = bsdf_f(B, si.wo, ls.wi, flags) * abs_dot(ls.wi, si.shading_n);
+                                    float sp = bsdf_pdf(B, si.wo, ls.wi, flags);
+                                    if (!f.is_black()) {
+                                        DRay sr = spawn_ray_to_hit(si.hit, ls.p1);
+                                        W.sh[2 * (size_t)(p)] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f); W.sh[2 * (size_t)(p) + 1] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.t_max);
+                                        ld = delta ? (f * ls.radiance / ls.pdf) : (f * ls.radiance * power_heuristic(ls.pdf, sp) / ls.pdf);
+                                        ps |= PS_SHADOW; sh_mask = 1u;
+                                    }
+                                }
+                                if (!delta) {
+                                    DScatter sc;
+                                    if (bsdf_sample(B, si.wo, us, flags, &sc)) {
+                                        Rgb f = sc.f * abs_dot(sc.wi, si.shading_n);
+                                        if (!f.is_black()) {
+                                            bool go = true;
+                                            if (sc.type & T_SPECULAR) mis_w = 1.0f;
+                                            else { float lp = light_pdf(S, Lt, si.hit, sc.wi); if (lp == 0.0f) go = false; else mis_w = power_heuristic(sc.pdf, lp); }
+                                            if (go) {
+                                                DRay mr = spawn_ray(si.hit, sc.wi);
+                                                W.ray[2 * (size_t)(p + W.n_paths)] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
+                                                W.ray[2 * (size_t)(p + W.n_paths) + 1] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
+                                                mis_f = f; mis_pdf = sc.pdf;
+                                                if (W.mis_any && Lt.kind == LK_INFINITE) { ps |= PS_MIS_ANY; push_mis_any = true; } else { ps |= PS_MIS; push_mis = true; }
+                                            }
+                                        }
+                                    }
+                                }
+                                W.pend0[p] = make_float4(ld.r, ld.g, ld.b, mis_w);
+                                W.pend1[p] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf);
+                            }
+                        }
+                        float4 lvA = make_float4(rad.r, rad.g, rad.b, 1.0f), lvB = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (depth + 1u < P.max_depth) {
+                            /* specular_reflect: the 2D sample is drawn before the match (mod.rs:52) */
+                            const V2 ur = rng.next2();
+                            DScatter sr;
+                            const bool has_r = bsdf_sample(B, si.wo, ur, T_REFL | T_SPECULAR, &sr) && !(abs_dot(sr.wi, si.shading_n) == 0.0f);
+                            const bool has_t = bsdf_num(B, T_TRANS | T_SPECULAR) > 0;
+                            if (has_t) err = FTN_ERR_UNSUPPORTED;              /* specular transmission: glass.rs:66 todo!() */
+                            else if (has_r) {
+                                lvA.w = sr.pdf; lvB = make_float4(sr.f.r, sr.f.g, sr.f.b, fabsf(dot(sr.wi, si.shading_n)));
+                                DRay nr = spawn_ray(si.hit, sr.wi);
+                                W.ray[2 * (size_t)(p)] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray[2 * (size_t)(p) + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
+                                alive = true; push_closest = true;
+                            }
+                        }
+                        W.dlA[(size_t)depth * W.n_paths + p] = lvA; W.dlB[(size_t)depth * W.n_paths + p] = lvB;
+                        depth += 1u;
+                        W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3);
+                        if (!alive && !(ps & PS_DIRECT)) { dl_unwind(P, W, p, depth, false, Rgb(0.0f)); ended = true; }      /* nothing pending: fold now */
+                    }
+                }
+                if (err && !ended) ended = true;
+                if (ended) { alive = false; ps &= ~(PS_DIRECT | PS_SHADOW | PS_MIS | PS_MIS_ANY); sh_mask = 0; push_closest = push_mis = push_mis_any = false; if (err) W.rad[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                ps = (ps & ~(PS_BOUNCE_MASK | PS_ALIVE)) | (depth & PS_BOUNCE_MASK) | (alive ? PS_ALIVE : 0u);
+                W.beta[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(ps));
+                if (!ended) W.rad[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(light_word));
+                push_active = alive || (ps & PS_DIRECT);
+            }
+        }
+        {
+            const bool pred[5] = {push_active, push_closest, push_mis, push_mis_any, push_mis_any};
+            const uint32_t val[5] = {p, p, p | WF_MIS_BIT, p | WF_MIS_BIT, 0u};
+            uint32_t* const qs[5] = {out_q, W.q_closest, W.q_closest, W.q_shadow, nullptr};
+            uint32_t* const cs[5] = {out_count, &W.counters[CTR(2)], &W.counters[CTR(2)], &W.counters[CTR(3)], &W.counters[CTR(10)]};
+            block_push<5>(pred, val, qs, cs);
+        }
+        /* shadow rays: slot p + l * n_paths (direct lighting: l = 0 only) -- queue entries are slots; the any-hit kernels read W.sh[2 * slot] */
+        for (uint32_t l = 0; l < (WHITTED ? WF_WH_MAX_LIGHTS : 1u); l++) {
+            const bool on = ((sh_mask >> l) & 1u) != 0;
+            const bool pred[1] = {on};
+            const uint32_t val[1] = {p + l * W.n_paths};
+            uint32_t* const qs[1] = {W.q_shadow};
+            uint32_t* const cs[1] = {&W.counters[CTR(3)]};
+            if (__syncthreads_or(on ? 1 : 0)) block_push<1>(pred, val, qs, cs);
+        }
+    }
+    if (err) atomicCAS(&P.stats->error, 0, err);
+}
+
 /* counters housekeeping between kernels (one tiny launch instead of host round trips) */
 __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -747,6 +980,8 @@ struct WavefrontState {
     uint32_t* host_counters = nullptr;    /* pinned */
     int n_cu = 256;
     /* four-box traversal (ftn_trace4.hip): launch plan of the current call and the global spill areas behind the LDS stacks */
+    /* buffers of the direct-lighting / Whitted mode (grow-only): level terms, and shadow-ray records / results / queue sized for one ray per light */
+    void* dl_mem[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dl_paths = 0; uint32_t dl_levels = 0, dl_slots = 0;
     Trace4Plan t4; bool t4_on = false;
     void* t4_spill_c = nullptr; void* t4_spill_a = nullptr; size_t t4_spill_c_bytes = 0, t4_spill_a_bytes = 0;
 };
@@ -762,6 +997,7 @@ void wavefront_destroy(WavefrontState* st) {
     if (st->ev_side) (void)hipEventDestroy(st->ev_side);
     if (st->side) (void)hipStreamDestroy(st->side);
     if (st->drain_sig) (void)hipFree(st->drain_sig);
+    for (void* m : st->dl_mem) if (m) (void)hipFree(m);
     if (st->t4_spill_c) (void)hipFree(st->t4_spill_c);
     if (st->t4_spill_a) (void)hipFree(st->t4_spill_a);
     if (st->host_counters) (void)hipHostFree(st->host_counters);
@@ -780,7 +1016,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
+        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 4 * n) /* up to WF_WH_MAX_LIGHTS shadow rays per path */) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -877,6 +1113,22 @@ static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, 
     else if (any) { if (count_b) { if (spheres) FTN_TR(true, true, true, 0); else FTN_TR(true, true, false, 0); } else { if (spheres) FTN_TR(true, false, true, 0); else FTN_TR(true, false, false, 0); } }
     else { if (count_b) { if (spheres) FTN_TR(false, true, true, 0); else FTN_TR(false, true, false, 0); } else { if (spheres) FTN_TR(false, false, true, 0); else FTN_TR(false, false, false, 0); } }
 #undef FTN_TR
+}
+
+/* buffers of k_wf_shade_dl for n paths, `levels` chain levels and `slots` shadow rays per path */
+static int wf_reserve_dl(WavefrontState* st, size_t n, uint32_t levels, uint32_t slots) {
+    if (n <= st->dl_paths && levels <= st->dl_levels && slots <= st->dl_slots) return FTN_OK;
+    for (void*& m : st->dl_mem) { if (m) (void)hipFree(m); m = nullptr; }
+    st->dl_paths = 0;
+    const size_t sl = std::max<uint32_t>(slots, 2u);                       /* (direct lighting: shadow results at [0, n), MIS-any results at [n, 2n)) */
+    WF_TRY(hipMalloc(&st->dl_mem[0], (size_t)levels * n * sizeof(float4)));          /* dlA */
+    WF_TRY(hipMalloc(&st->dl_mem[1], (size_t)levels * n * sizeof(float4)));          /* dlB */
+    WF_TRY(hipMalloc(&st->dl_mem[2], (size_t)slots * n * sizeof(float4)));           /* whT */
+    WF_TRY(hipMalloc(&st->dl_mem[3], 2 * (size_t)slots * n * sizeof(float4)));       /* shadow-ray records */
+    WF_TRY(hipMalloc(&st->dl_mem[4], sl * n));                                       /* occluded */
+    WF_TRY(hipMalloc(&st->dl_mem[5], sl * n * sizeof(uint32_t)));                    /* any-hit queue */
+    st->dl_paths = n; st->dl_levels = levels; st->dl_slots = slots;
+    return FTN_OK;
 }
 
 static int wf_state_init(WavefrontState** state) {
@@ -1000,7 +1252,17 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (rc) { wf_free(st); return rc; }
     if ((rc = trace4_prepare(st, P.S))) return rc;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
+    const bool dl_mode = P.integrator_kind != FTN_INTEGRATOR_PATH;          /* DirectLightingIntegrator / WhittedIntegrator: k_wf_shade_dl */
+    const bool whitted = P.integrator_kind == FTN_INTEGRATOR_WHITTED;
+    if (dl_mode) {
+        if (P.S.n_textures) { g_wf_err = "the wavefront pipeline runs DirectLightingIntegrator / WhittedIntegrator for scenes without textures"; return FTN_ERR_UNSUPPORTED; }
+        if (whitted && P.S.n_lights > WF_WH_MAX_LIGHTS) { g_wf_err = "the wavefront pipeline runs WhittedIntegrator for up to 4 lights"; return FTN_ERR_UNSUPPORTED; }
+        const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(P.max_depth, WF_DL_MAX)), slots = whitted ? std::max<uint32_t>(P.S.n_lights, 1u) : 1u;
+        if ((rc = wf_reserve_dl(st, st->cap_paths, levels, slots))) return rc;
+        st->W.dlA = (float4*)st->dl_mem[0]; st->W.dlB = (float4*)st->dl_mem[1]; st->W.whT = (float4*)st->dl_mem[2];
+    }
     WfBuffers W = st->W;
+    if (dl_mode) { W.sh = (float4*)st->dl_mem[3]; W.occluded = (unsigned char*)st->dl_mem[4]; W.q_shadow = (uint32_t*)st->dl_mem[5]; }
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
@@ -1117,7 +1379,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             {
                 const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));
                 const bool tex = P.S.n_textures != 0;
-                if (!knob("FTN_SHADE_SPECIALISE", 1)) {
+                if (dl_mode) {
+                    if (whitted) hipLaunchKernelGGL((k_wf_shade_dl<true>), sgrid, dim3(256), 0, stream, P, W, in_q);
+                    else hipLaunchKernelGGL((k_wf_shade_dl<false>), sgrid, dim3(256), 0, stream, P, W, in_q);
+                } else if (!knob("FTN_SHADE_SPECIALISE", 1)) {
                     if (tex) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
                     else hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
                 } else {   /* one launch per material type present in the scene + one for the classes without a BSDF */

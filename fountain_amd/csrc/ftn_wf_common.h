@@ -39,6 +39,9 @@ struct WfBuffers {
     /* rays the four-box kernels hand back to the reference-order kernels (a direction component of zero: see ftn_trace4.hip), queue
      * entries as in the queue they came from; counts at CTR(32) closest / CTR(33) any-hit, slice heads at CTR(40..47) / CTR(48..55) */
     uint32_t *q_exc_closest, *q_exc_any;
+    /* DirectLightingIntegrator / WhittedIntegrator (k_wf_shade_dl): per-level terms of the nested product, level-major: dlA[d * n_paths + p] =
+     * {local.rgb, pdf}, dlB = {f.rgb, |cos|}; whT[l * n_paths + p] = Whitted's term of light l (added if its shadow ray is unoccluded) */
+    float4 *dlA, *dlB, *whT;
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
 

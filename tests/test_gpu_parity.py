@@ -603,3 +603,60 @@ def test_environment_maps_of_any_size(gpu, orc_det, shape, pipeline):
     (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, lambda be: _env_scene(be, tex), PathIntegrator.new(4, 1.0), RandomSampler(4, 0, indexed=True), pipeline)
     assert_film_equal(px, pxo, st["spill_samples"], "env map %dx%d" % shape)
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and rgb.max() > 0.5
+
+
+# ------------------------------------------------------------------ DirectLightingIntegrator / WhittedIntegrator through the wavefront queues
+def _mirror_hall(be):
+    """two facing mirrors, a mirror sphere and matte / plastic / metal objects under point + area lights: specular chains up to the depth limit"""
+    b = SceneBuilder(be)
+    b.light_source("point", I=(25, 25, 25), from_=(0.3, -0.2, 2.6))
+    b.material("matte", Kd=(0.6, 0.6, 0.6))
+    scenes._quad(b, (-3, -3, 0), (3, -3, 0), (3, 3, 0), (-3, 3, 0))
+    b.material("mirror", Kr=(0.9, 0.9, 0.9))
+    scenes._quad(b, (-3, 3, 0), (3, 3, 0), (3, 3, 3), (-3, 3, 3))
+    scenes._quad(b, (3, -3, 0), (-3, -3, 0), (-3, -3, 3), (3, -3, 3))
+    b.attribute_begin(); b.material("mirror"); b.translate((1.2, 0.5, 0.6)); b.shape("sphere", radius=0.6); b.attribute_end()
+    b.attribute_begin(); b.material("plastic", Kd=(0.3, 0.1, 0.1), Ks=(0.4, 0.4, 0.4), roughness=0.05); b.translate((-1.0, 0.2, 0.5)); b.shape("sphere", radius=0.5); b.attribute_end()
+    b.attribute_begin(); b.material("metal", eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.2); b.translate((0.0, 1.6, 0.4)); b.shape("sphere", radius=0.4); b.attribute_end()
+    b.attribute_begin(); b.material("matte", Kd=(0, 0, 0)); b.area_light_source("diffuse", L=(6, 6, 6)); b.translate((-1.5, -1.0, 2.5)); b.shape("sphere", radius=0.3); b.attribute_end()
+    cam = PerspectiveCamera.look_at(be, (0.5, -2.6, 1.6), (0.2, 1.0, 0.7), (0, 0, 1), (88, 64), fov=60.0)
+    return b, cam, (88, 64)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "materials", "mirror_hall", "cubes27", "furnace"])
+@pytest.mark.parametrize("which", ["direct", "whitted"])
+def test_direct_lighting_and_whitted_on_the_wavefront_pipeline(gpu, orc_det, scene, which):
+    """the other two estimators as wavefront stages (k_wf_shade_dl): the nested product f * Li(child) * |cos| / pdf kept per depth and folded
+    innermost first, so films are bit-equal to the oracle's recursion and to the megakernel; ray counts equal"""
+    make = {"cornell": lambda be: scenes.cornell(be, res=64), "materials": _materials_scene, "mirror_hall": _mirror_hall,
+            "cubes27": lambda be: scenes.instanced_cubes(be, n_copies=27, res=(96, 96), env_n=32), "furnace": scenes.furnace}[scene]
+    integ = DirectLightingIntegrator(5) if which == "direct" else WhittedIntegrator(5)
+    smp = RandomSampler(4, 0, indexed=True)
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, make, integ, smp, WAVE)
+    assert_film_equal(px, pxo, st["spill_samples"], "%s %s, wavefront" % (scene, which))
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and st["camera_samples"] == sto["camera_samples"]
+    assert np.isfinite(rgb).all() and rgb.max() > 0
+    mega = scenes.render(gpu, *make(gpu), integ, smp, backend_kwargs=dict(pipeline=MEGA))
+    assert_film_equal(px, mega[1], st["spill_samples"], "%s %s, wavefront vs megakernel" % (scene, which))
+    auto = scenes.render(gpu, *make(gpu), integ, smp)                          # AUTO picks the wavefront for the indexed sampler
+    assert np.array_equal(bits(auto[1]), bits(scenes.render(gpu, *make(gpu), integ, smp, backend_kwargs=dict(pipeline=WAVE))[1]))
+
+
+def test_wavefront_direct_lighting_limits(gpu):
+    """what the queues do not take is refused (explicit request) or left to the megakernel (AUTO): Whitted with more than four lights
+    (one shadow-ray slot per light and path); the reference's tile-serial sampler"""
+    def many_lights(be):
+        b, cam, res = scenes.cornell(be, res=32)
+        for k in range(4):
+            b.light_source("point", I=(1, 1, 1), from_=(0.1 * k, 0, 0.5))
+        return b, cam, res
+    smp = RandomSampler(2, 0, indexed=True)
+    with pytest.raises(FountainError) as e:
+        scenes.render(gpu, *many_lights(gpu), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))
+    assert e.value.code == A.FTN_ERR_UNSUPPORTED
+    a = scenes.render(gpu, *many_lights(gpu), WhittedIntegrator(3), smp)                                       # AUTO -> megakernel
+    m = scenes.render(gpu, *many_lights(gpu), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
+    assert np.array_equal(bits(a[1]), bits(m[1]))
+    scenes.render(gpu, *many_lights(gpu), DirectLightingIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))   # one light per hit: any number of lights
+    with pytest.raises(FountainError):
+        scenes.render(gpu, *scenes.cornell(gpu, res=32), DirectLightingIntegrator(3), RandomSampler(2, 0), backend_kwargs=dict(pipeline=WAVE))

@@ -1,5 +1,5 @@
-"""Measurement for DESIGN.md section 8: DirectLightingIntegrator / WhittedIntegrator run in the per-pixel megakernel.
-How far is that from the wavefront pipeline on the same scenes?  Prints Mrays/s (kernel time) per integrator and pipeline."""
+"""Measurement for DESIGN.md section 8: the three integrators on the wavefront pipeline and in the per-pixel megakernel.
+Prints Mrays/s (kernel time) per integrator and pipeline."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,8 @@ def run(name, make, spp):
     b, cam, res = make(gpu)
     sc = b.create_scene()
     for label, integ, pl in (("path, wavefront", PathIntegrator(5, 1.0), WAVE), ("path, megakernel", PathIntegrator(5, 1.0), MEGA),
-                             ("direct lighting (depth 5), megakernel", DirectLightingIntegrator(5), MEGA), ("whitted (depth 5), megakernel", WhittedIntegrator(5), MEGA)):
+                             ("direct lighting (depth 5), wavefront", DirectLightingIntegrator(5), WAVE), ("direct lighting (depth 5), megakernel", DirectLightingIntegrator(5), MEGA),
+                             ("whitted (depth 5), wavefront", WhittedIntegrator(5), WAVE), ("whitted (depth 5), megakernel", WhittedIntegrator(5), MEGA)):
         si = SamplerIntegrator(cam, integ)
         best = None
         for rep in range(3):
