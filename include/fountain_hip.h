@@ -256,17 +256,19 @@ typedef struct ftn_tile_range {
 } ftn_tile_range;
 
 enum {
-    FTN_PIPELINE_AUTO = 0,
-    FTN_PIPELINE_MEGAKERNEL = 1,   /* one lane walks a whole path              */
-    FTN_PIPELINE_WAVEFRONT = 2     /* SoA queues, trace / shade kernels         */
+    FTN_PIPELINE_AUTO = 0,         /* the wavefront pipeline whenever it takes the request, else the megakernel                                   */
+    FTN_PIPELINE_MEGAKERNEL = 1,   /* one lane walks a whole path (any sampler, any integrator)                                                   */
+    FTN_PIPELINE_WAVEFRONT = 2     /* SoA queues, trace / shade kernels: FTN_SAMPLER_INDEXED; the path integrator always, direct lighting and
+                                      Whitted for scenes without textures (Whitted: at most 4 lights); FTN_ERR_UNSUPPORTED otherwise              */
 };
 
 typedef struct ftn_render_options {
     uint32_t pipeline;        /* FTN_PIPELINE_*                                                 */
     int32_t device;           /* HIP device ordinal; -1 = current                               */
     uint32_t count_traffic;   /* 1: also tally nodes visited / prims tested with the reference's traversal for every ray (slower; equals the
-                                    oracle's tally); 2: tally what the production configuration really walks (MIS rays toward an
-                                    infinite light go through the any-hit kernel, see ftn_stats.mis_rays_any_hit)        */
+                                    oracle's tally); 2: tally what the production configuration really walks: four-box records
+                                    (ftn_stats.quad_records) and triangle tests, MIS rays toward an infinite light through the any-hit
+                                    kernel (ftn_stats.mis_rays_any_hit)                                                  */
     uint32_t _pad;
 } ftn_render_options;
 
