@@ -93,6 +93,9 @@ struct DScene {
      * built).  quad_stack_bound: upper bound of the entries a walk can have pending. */
     const float4* quad;
     uint32_t n_quads, quad_stack_bound;
+    /* shading class of every primitive (k_wf_classify, ftn_wavefront.hip): 2 + material type, 7 for a primitive without material.  One
+     * byte per primitive -- cache resident where prim_info (32 bytes per primitive) is not.  Never NULL for a scene with primitives. */
+    const unsigned char* prim_class;
 };
 
 struct DCamera {

@@ -608,7 +608,7 @@ struct ftn_scene {
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
     DevBuf<float4> nodes, geom, fat, srec, quad; DevBuf<uint4> prim_info; DevBuf<float> N, UV, T; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
-    DevBuf<uint32_t> inf_lights; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
+    DevBuf<uint32_t> inf_lights; DevBuf<unsigned char> prim_class; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
     DevBuf<float4> accA, accB, accC; DevBuf<DTile> tiles; DevBuf<DevStats> stats; size_t acc_pixels = 0;
@@ -616,7 +616,7 @@ struct ftn_scene {
     WavefrontState* wf = nullptr;
     std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
-        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); prim_info.release(); N.release(); UV.release(); T.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release();
+        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); prim_info.release(); N.release(); UV.release(); T.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release(); prim_class.release();
         for (auto& b : misc) b.release();
         for (auto& b : misc4) b.release();
         textures.release(); mtex.release(); images.release(); texels.release();
@@ -744,6 +744,11 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         if (!textured) material_finalize(mats[i]);
     }
     if ((rc = sc->materials.upload(mats.data(), mats.size()))) return rc;
+    {   /* shading class per primitive (DScene::prim_class) */
+        std::vector<unsigned char> cls(np);
+        for (size_t i = 0; i < np; i++) { const int m = (int)info[2 * i].x; cls[i] = (unsigned char)(m < 0 || (size_t)m >= mats.size() ? 7u : std::min<uint32_t>(2u + mats[(size_t)m].type, 7u)); }
+        if ((rc = sc->prim_class.upload(cls.data(), cls.size()))) return rc;
+    }
     /* lights */
     std::vector<DLight> lights(hs.light_kind.size());
     std::vector<uint32_t> inf;
@@ -827,7 +832,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.T = sc->T.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
-    D.srec = sc->srec.p;
+    D.srec = sc->srec.p; D.prim_class = sc->prim_class.p;
     D.quad = sc->quad.p; D.n_quads = n_quads; D.quad_stack_bound = quad_bound;
     D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }

@@ -169,7 +169,7 @@ __device__ inline void t4_record_step(const DScene& S, const RaySetup& R, T4Stac
 }
 
 template <bool COUNT, bool SPHERES, int BURST>
-__global__ void __launch_bounds__(256) k_wf_trace4(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head, DevStats* stats,
+__global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head, DevStats* stats,
                                                    uint32_t refill, uint32_t leaf_batch, uint32_t chunk_max, uint32_t lds_entries, uint2* __restrict__ spill, uint32_t spill_levels) {
     extern __shared__ uint2 lds_stack2[];
     T4Stack<uint2> St;

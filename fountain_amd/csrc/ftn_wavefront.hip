@@ -56,13 +56,13 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
         W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
-        W.p_film[i] = make_float2(p_film.x, p_film.y);
+        /* (the film position is not kept: k_wf_accumulate draws it again from the sample's key) */
         /* queue order = path order: tile, pixel, sample.  A wave of the first trace (and of the first shading pass, and of the shadow
          * rays it emits) covers a few pixels instead of 64, each XCD's slice of the queue is a part of the image rather than one whole
          * sample of it, and the path state is still read in order. */
         const uint32_t pix = tile.valid_off + (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
         const uint32_t qi = pix * W.samples + s;
-        W.q_active[0][qi] = i;
+        W.q_active[0][qi] = i | (P.max_depth == 0 ? WF_Q_DEPTH : 0u);
         W.q_closest[qi] = i;
     }
 }
@@ -335,14 +335,13 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
  * Two passes (count, scatter) with block-level ballots; class segments start at multiples of 256 so that every shade
  * workgroup sees a single class and its branches on hit/material are wave-uniform. */
 #define WF_NCLASS 8
-__device__ inline uint32_t wf_class_of(const RenderParams& P, const WfBuffers& W, uint32_t p) {
-    const uint32_t ps = __float_as_uint(W.beta[p].w);
-    if (!(ps & PS_ALIVE)) return 0u;
-    const int prim = W.hit_prim[p];
-    if (prim < 0 || (ps & PS_BOUNCE_MASK) >= P.max_depth) return 1u;
-    const int mat = (int)P.S.prim_info[2 * prim].x;
-    if (mat < 0) return 7u;
-    return 2u + P.S.materials[mat].type;
+__device__ inline uint32_t wf_class_of(const RenderParams& P, const WfBuffers& W, uint32_t entry) {
+    /* an active-queue entry says whether the path has ended / reached max_depth (WF_Q_*), hit_prim is a dense array, the primitive's
+     * class is a byte (DScene::prim_class): nothing here gathers from the path state or the 32-byte prim_info records */
+    if (entry & WF_Q_FIN) return 0u;
+    const int prim = W.hit_prim[entry & WF_Q_ID_MASK];
+    if (prim < 0 || (entry & WF_Q_DEPTH)) return 1u;
+    return P.S.prim_class[prim];
 }
 /* Each class owns a segment of `seg_cap` slots in q_sorted (worst case: every path in one class).  A workgroup classifies all of
  * its rounds first (class codes and per-wave counts stay in LDS), reserves its slots with ONE global atomic per class -- with one
@@ -386,7 +385,7 @@ __global__ void __launch_bounds__(256) k_wf_classify(RenderParams P, WfBuffers W
             if (c < WF_NCLASS) {
                 uint32_t off = s_base[c] + s_pre[r][c];
                 for (uint32_t w2 = 0; w2 < wave; w2++) off += s_cnt[r][c][w2];
-                W.q_sorted[(size_t)c * W.seg_cap + off + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = W.q_active[in_q][qi];
+                W.q_sorted[(size_t)c * W.seg_cap + off + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = W.q_active[in_q][qi] & WF_Q_ID_MASK;
             }
         }
         __syncthreads();
@@ -401,6 +400,12 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 #ifndef FTN_SHADE_MIN_WAVES
 #define FTN_SHADE_MIN_WAVES 1
 #endif
+#ifndef FTN_SHADE_WAVES_MATTE
+#define FTN_SHADE_WAVES_MATTE 3
+#endif
+#ifndef FTN_SHADE_WAVES_OTHER
+#define FTN_SHADE_WAVES_OTHER 3
+#endif
 /* MT: -1 = every class in `class_mask`, material type read at run time (textured scenes);  0..4 = ONE material class, its BSDF code
  * specialised at compile time (fewer registers: 3 waves/SIMD instead of 2, 4 for mirrors);  -2 = the classes without a BSDF
  * (finished paths, misses / depth limit, null materials), the material branch compiled out. */
@@ -408,7 +413,7 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
  * loads instead of one gather per field and lane) and the point / distant / area-light code is compiled out; every value computed
  * is the one the generic kernel computes for such a scene. */
 template <bool TEX, int MT, bool ENV>
-__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : 3))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask) {
+__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : (MT == 0 ? FTN_SHADE_WAVES_MATTE : FTN_SHADE_WAVES_OTHER)))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask) {
     const DScene& S = P.S;
     /* virtual, 256-aligned concatenation of the selected class segments: a workgroup never straddles two classes */
     uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
             sorted_idx = c * W.seg_cap + (qi - cb);
         }
         bool push_active = false, push_closest = false, push_mis = false, push_shadow = false, push_mis_any = false;
-        uint32_t p = 0;
+        uint32_t p = 0, active_entry = 0;
         if (have) {
             p = W.q_sorted[sorted_idx];
             float4 bq = W.beta[p], lq = W.rad[p];
@@ -474,8 +479,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 ps &= ~(PS_DIRECT | PS_SHADOW | PS_MIS | PS_MIS_ANY);
             }
             if (!(ps & PS_ALIVE)) {
-                W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);     /* path finished: final radiance */
-                W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));
+                W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);     /* path finished: final radiance (the rest of its state is never read again) */
             } else {
                 const float4 ro = W.ray[2 * (size_t)(p)], rdv = W.ray[2 * (size_t)(p) + 1];
                 DRay ray0; ray0.o = V3(ro.x, ro.y, ro.z); ray0.d = V3(rdv.x, rdv.y, rdv.z); ray0.t_max = rdv.w; ray0.time = 0.0f;
@@ -587,17 +591,18 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                             } else alive = false;
                         }
                     }
-                    W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3);
+                    if (alive) { W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3); }      /* (an ended path draws nothing more) */
                 }
                 ps = (ps & ~(PS_BOUNCE_MASK | PS_ALIVE)) | (bounces & PS_BOUNCE_MASK) | (alive ? PS_ALIVE : 0u);
-                W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));
-                W.rad[p] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word));
                 push_active = alive || (ps & PS_DIRECT);        /* finished paths with a pending direct term come back once */
+                if (push_active) W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));        /* (a retired path's throughput is never read again) */
+                W.rad[p] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word));
+                active_entry = p | (alive ? (bounces >= P.max_depth ? WF_Q_DEPTH : 0u) : WF_Q_FIN);
             }
         }
         {
             const bool pred[6] = {push_active, push_closest, push_mis, push_shadow, push_mis_any, push_mis_any};
-            const uint32_t val[6] = {p, p, p | WF_MIS_BIT, p, p | WF_MIS_BIT, 0u};
+            const uint32_t val[6] = {active_entry, p, p | WF_MIS_BIT, p, p | WF_MIS_BIT, 0u};
             uint32_t* const qs[6] = {out_q, W.q_closest, W.q_closest, W.q_shadow, W.q_shadow, nullptr};        /* the last "queue" only counts (CTR(10)): MIS rays traced as any-hit */
             uint32_t* const cs[6] = {out_count, &W.counters[CTR(2)], &W.counters[CTR(2)], &W.counters[CTR(3)], &W.counters[CTR(3)], &W.counters[CTR(10)]};
             block_push<6>(pred, val, qs, cs);
@@ -663,7 +668,7 @@ __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W
         }
         bool push_active = false, push_closest = false, push_mis = false, push_mis_any = false;
         uint32_t sh_mask = 0;                                    /* shadow rays this path emits: bit l = the ray in slot p + l * n_paths (Whitted: one per light) */
-        uint32_t p = 0;
+        uint32_t p = 0, active_entry = 0;
         if (have) {
             p = W.q_sorted[sorted_idx];
             const float4 bq = W.beta[p], lq = W.rad[p];
@@ -817,11 +822,12 @@ __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W
                 W.beta[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(ps));
                 if (!ended) W.rad[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(light_word));
                 push_active = alive || (ps & PS_DIRECT);
+                active_entry = p | (alive ? 0u : WF_Q_FIN);
             }
         }
         {
             const bool pred[5] = {push_active, push_closest, push_mis, push_mis_any, push_mis_any};
-            const uint32_t val[5] = {p, p, p | WF_MIS_BIT, p | WF_MIS_BIT, 0u};
+            const uint32_t val[5] = {active_entry, p, p | WF_MIS_BIT, p | WF_MIS_BIT, 0u};
             uint32_t* const qs[5] = {out_q, W.q_closest, W.q_closest, W.q_shadow, nullptr};
             uint32_t* const cs[5] = {out_count, &W.counters[CTR(2)], &W.counters[CTR(2)], &W.counters[CTR(3)], &W.counters[CTR(10)]};
             block_push<5>(pred, val, qs, cs);
@@ -885,7 +891,6 @@ __device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 
 #define WF_ACC_CHUNK 8u
 __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers W) {
     __shared__ float4 s_rad[256 * WF_ACC_CHUNK];
-    __shared__ float2 s_pf[256 * WF_ACC_CHUNK];
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t spill = 0, bc = 0, cam = 0; int err = 0;
     bool valid = false, in_crop = false; int px = 0, py = 0; size_t ai = 0;
@@ -911,7 +916,7 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
         for (uint32_t e = threadIdx.x; e < 256u * n; e += 256u) {                /* n consecutive samples of slot e / n */
             const uint32_t sl = e / n, k = e - sl * n;
             const size_t p = block_first + (size_t)sl * W.samples + s0 + k;
-            if (p < W.n_paths) { s_rad[sl * WF_ACC_CHUNK + k] = W.rad[p]; s_pf[sl * WF_ACC_CHUNK + k] = W.p_film[p]; }
+            if (p < W.n_paths) s_rad[sl * WF_ACC_CHUNK + k] = W.rad[p];
         }
         __syncthreads();
         if (valid) {
@@ -919,8 +924,10 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
                 const float4 l = s_rad[threadIdx.x * WF_ACC_CHUNK + k];
                 Rgb L(l.x, l.y, l.z);
                 if (L.has_nans()) err = FTN_ERR_NAN_RADIANCE;
-                const float2 pf = s_pf[threadIdx.x * WF_ACC_CHUNK + k];
-                wf_film_add(P, F, V2(pf.x, pf.y), L, in_crop ? px : (-2147483647), py, &acc, &spill, &bc);
+                /* the sample's film position: the first two draws of its stream, exactly as k_wf_generate made them (sampler/mod.rs:41-48) */
+                Rng crng; crng.seed(indexed_key(P.seed, px, py, W.first_sample + s0 + k));
+                const V2 j = crng.next2();
+                wf_film_add(P, F, V2((float)px + j.x, (float)py + j.y), L, in_crop ? px : (-2147483647), py, &acc, &spill, &bc);
                 cam++;
             }
         }
@@ -959,14 +966,6 @@ __global__ void __launch_bounds__(256) k_wf_ray_keys(DScene S, WfBuffers W, cons
     const uint32_t m = spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);       /* NaN / inf -> cell 0: still a valid key */
     const uint32_t oct = (b.x < 0.0f ? 1u : 0u) | (b.y < 0.0f ? 2u : 0u) | (b.z < 0.0f ? 4u : 0u);
     keys[i] = (m << 3) | oct;
-}
-
-/* experiment (FTN_WF_SORT_HIT=1): order the active queue by the primitive each path just hit -- BVH order is spatial
- * order -- so that shading, and the shadow / MIS / continuation rays it emits, run in spatial order */
-__global__ void __launch_bounds__(256) k_wf_hit_keys(WfBuffers W, const uint32_t* __restrict__ queue, uint32_t count, uint32_t* __restrict__ keys) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
-    keys[i] = (uint32_t)(W.hit_prim[queue[i]] + 1);            /* a miss (-1) sorts first */
 }
 
 struct WavefrontState {
@@ -1014,7 +1013,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
     WfBuffers& W = st->W; int rc;
     if ((rc = wf_alloc(st, &W.ray, 4 * n)) || (rc = wf_alloc(st, &W.hit, 2 * n)) || (rc = wf_alloc(st, &W.hit_prim, 2 * n)) ||
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
-        (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) || (rc = wf_alloc(st, &W.p_film, n)) ||
+        (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
         (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 4 * n) /* up to WF_WH_MAX_LIGHTS shadow rays per path */) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
     st->cap_paths = n;
@@ -1283,7 +1282,6 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
      * kernels are instruction-issue bound and gain as much as the sort (and its per-bounce read-back of the queue lengths) costs: 354.1 vs
      * 353.4 ms per step on the config-5 scene, and it loses 6 % on the smaller configurations (profiles/r02).  Off by default. */
     const uint32_t sort_bits = knob("FTN_WF_SORT", 0) ? std::min<uint32_t>(std::max<uint32_t>(knob("FTN_WF_SORT_BITS", 7), 1u), 9u) : 0u;
-    const bool sort_hit = knob("FTN_WF_SORT_HIT", 0) != 0;
     uint32_t n_active = 0;                 /* length of the active queue the next classify reads (known from the previous bounce's poll) */
     int ev_used = 0;
     struct Span { int a, b, kind; };
@@ -1359,20 +1357,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
                 hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
-                uint32_t* const q_in = W.q_active[in_q];
-                if (sort_hit && it > 0 && n_active >= 16384u && !beside) {      /* experiment: active queue in hit-primitive order (scratch: the exception queues, idle between traces) */
-                    uint32_t* k_in = W.q_exc_closest, *k_out = W.q_exc_closest + st->cap_paths, *v_out = W.q_exc_any;
-                    hipLaunchKernelGGL(k_wf_hit_keys, dim3((n_active + 255) / 256), dim3(256), 0, stream, W, q_in, n_active, k_in);
-                    int end_bit = 1; while ((1ull << end_bit) <= (unsigned long long)P.S.n_prims) end_bit++;
-                    size_t need = 0;
-                    hipcub::DoubleBuffer<uint32_t> keys(k_in, k_out), vals(q_in, v_out);
-                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, vals, (int)n_active, 0, end_bit, stream));
-                    if (need > st->sort_tmp_bytes) { if (st->sort_tmp) (void)hipFree(st->sort_tmp); st->sort_tmp = nullptr; st->sort_tmp_bytes = 0; WF_TRY(hipMalloc(&st->sort_tmp, need)); st->sort_tmp_bytes = need; }
-                    WF_TRY(hipcub::DeviceRadixSort::SortPairs(st->sort_tmp, need, keys, vals, (int)n_active, 0, end_bit, stream));
-                    W.q_active[in_q] = vals.Current();
-                }
                 hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
-                W.q_active[in_q] = q_in;
             }
             if (beside) WF_TRY(hipStreamWaitEvent(stream, st->ev_side, 0));     /* shading needs the occlusion results (classify above did not) */
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);

@@ -28,8 +28,7 @@ struct WfBuffers {
     float4 *rad;                /* L.xyz, bits(light index of the pending direct term) */
     ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
-    float2* p_film;             /* the camera sample's film position (for the in-order film add) */
-    uint32_t *q_active[2], *q_closest, *q_shadow;
+    uint32_t *q_active[2], *q_closest, *q_shadow;   /* active-queue entries carry WF_Q_FIN / WF_Q_DEPTH in their top bits */
     uint32_t* q_sorted;         /* the active queue grouped by shading class (material-sorted shading) */
     uint32_t* cls;              /* per-class path counts, one 128-byte line each (CTR(k)) */
     uint32_t seg_cap;           /* capacity of one class segment of q_sorted */
@@ -44,6 +43,12 @@ struct WfBuffers {
     float4 *dlA, *dlB, *whT;
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
+
+/* flags in an ACTIVE-queue entry (path ids stay below 2^28: wavefront_render): what k_wf_classify needs to know about the path without
+ * touching its state */
+#define WF_Q_FIN 0x80000000u        /* the path has ended and only comes back for its pending direct term (class 0) */
+#define WF_Q_DEPTH 0x40000000u      /* alive, but its bounce count has reached max_depth: emission only, whatever it hits (class 1) */
+#define WF_Q_ID_MASK 0x0fffffffu
 
 #define CTR(i) ((i) * 32)
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }

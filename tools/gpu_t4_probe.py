@@ -24,7 +24,7 @@ reps = int(os.environ.get("PROBE_REPS", "2"))
 
 gpu = default_backend()
 t0 = time.time()
-b, cam, r = scenes.instanced_cubes(gpu, n_copies=copies, res=(res, res))
+b, cam, r = scenes.instanced_cubes(gpu, n_copies=copies, res=(res, res), env_n=int(os.environ.get("PROBE_ENV_N", "1024")))
 sc = b.create_scene()
 info = sc.info()
 print("scene: %d prims, %d nodes, depth %d, built in %.1f s" % (info["n_prims"], info["n_nodes"], info["max_depth"], time.time() - t0), flush=True)

@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["fountain_amd/csrc/ftn_trace4.hip", "fountain_amd/csrc/ftn_wavefront.hip", "fountain_amd/csrc/ftn_wf_common.h", "fountain_amd/csrc/ftn_device.h",
            "fountain_amd/csrc/ftn_kernels.hip", "fountain_amd/csrc/ftn_host.cpp", "fountain_amd/csrc/ftn_math.h", "fountain_amd/csrc/detmath.h", "fountain_amd/csrc/ftn_texture.h"]
 PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum"]),
+          ("tcc2", ["TCC_REQ_sum", "TCC_READ_sum", "TCC_WRITE_sum", "TCC_ATOMIC_sum"]), ("tcc3", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]),
           ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY"]),
           ("grbm", ["GRBM_GUI_ACTIVE"])]
 
@@ -62,6 +63,7 @@ def main():
     sums = collections.defaultdict(lambda: collections.defaultdict(float))       # group -> counter -> sum over the timed step
     launches = collections.defaultdict(int)
     dominant = collections.defaultdict(float)
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))   # short kernel name -> counter -> sum (production instantiations only)
     bench_line = None
     env = dict(os.environ, TMPDIR="/tmp")
     for name, ctrs in PASSES:
@@ -83,11 +85,14 @@ def main():
                 if g is None or counting:
                     continue
                 sums[g][row["Counter_Name"]] += float(row["Counter_Value"])
+                short = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("ftn::", "")
+                per_kernel[short][row["Counter_Name"]] += float(row["Counter_Value"])
                 if g == "closest" and "k_wf_trace4" in row["Kernel_Name"]:
                     dominant[row["Counter_Name"]] += float(row["Counter_Value"])
                 if name == "fetch" and (row["Dispatch_Id"], g) not in seen:
                     seen.add((row["Dispatch_Id"], g))
                     launches[g] += 1
+                    per_kernel[short]["launches"] += 1
                     if g == "closest" and "k_wf_trace4" in row["Kernel_Name"]:
                         launches["closest_dominant"] += 1
         subprocess.run(["rm", "-rf", d])
@@ -113,6 +118,10 @@ def main():
                                "valu_busy": (dominant.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * dominant["GRBM_GUI_ACTIVE"] / 8.0)) if dominant.get("GRBM_GUI_ACTIVE") else None,
                                "wave_cycles_waiting_on_memory": (dominant.get("SQ_WAIT_ANY", 0.0) / dominant["SQ_WAVE_CYCLES"]) if dominant.get("SQ_WAVE_CYCLES") else None},
            "groups": groups,
+           "kernels": {k: {"launches_per_step": int(c.get("launches", 0)), "hbm_bytes_per_step": hbm_bytes(c), "read_bytes_per_step": c.get("FETCH_SIZE", 0.0) * 2048.0,
+                           "write_bytes_per_step": c.get("WRITE_SIZE", 0.0) * 1024.0,
+                           "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0),
+                           "valu_wave_instructions": c.get("SQ_INSTS_VALU", 0.0), "gpu_cycles": c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0, "counters": dict(c)} for k, c in sorted(per_kernel.items())},
            "method": "rocprofv3 --pmc (one counter group per pass: " + "; ".join("+".join(c) for _, c in PASSES) + ") --kernel-trace over `python bench.py --steps 1 --warmup 0 "
                      "--no-cpu-baseline --no-count-step`; production kernel instantiations only (the bench's counting step runs other instantiations); HBM-side bytes = FETCH_SIZE KiB x 1024 x 2 + "
                      "WRITE_SIZE KiB x 1024 (gfx950: 128-byte read requests are tallied at 64 B; cross-checked against TCC_EA0_RDREQ_128B x 128 B in the same file)"}
@@ -120,6 +129,8 @@ def main():
     print(json.dumps({k: (v if not isinstance(v, dict) else "...") for k, v in out.items()}))
     for g, v in groups.items():
         print(g, json.dumps(v))
+    for k, v in out["kernels"].items():
+        print(k, json.dumps(v))
 
 
 if __name__ == "__main__":
