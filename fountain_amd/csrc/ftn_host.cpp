@@ -1082,6 +1082,10 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     s->spill_acc_dirty = ds.bc_writes != 0;
     ds.rays_closest += wt.mis_any_rays; ds.rays_any -= wt.mis_any_rays;       /* they are Scene::intersect calls in the reference's accounting */
     stats_out(ds, st, ms);
+    if (ds.t4_occ[0] | ds.t4_occ[7]) { const char* dbg = getenv("FTN_WF_DEBUG"); if (dbg && atoi(dbg)) {     /* lane occupancy of the counting builds (experiments) */
+        for (int k = 0; k < 2; k++) { const unsigned long long* o = &ds.t4_occ[7 * k]; if (!o[0]) continue;
+            fprintf(stderr, "[wf] %s four-box trace: %llu control rounds; %llu record steps with %.1f of 64 lanes; %llu leaf steps with %.1f lanes; %llu refills of %.1f lanes\n", k ? "any-hit" : "closest-hit",
+                    o[0], o[1], o[1] ? (double)o[2] / (double)o[1] : 0.0, o[3], o[3] ? (double)o[4] / (double)o[3] : 0.0, o[5], o[5] ? (double)o[6] / (double)o[5] : 0.0); } } }
     if (st) {
         st->trace_ms = wt.trace_ms; st->trace_launches = wt.trace_launches; st->mis_rays_any_hit = wt.mis_any_rays;
         st->any_ms = wt.any_ms; st->any_launches = wt.any_launches; st->shade_ms = wt.shade_ms; st->shade_launches = wt.shade_launches; st->sort_ms = wt.sort_ms;

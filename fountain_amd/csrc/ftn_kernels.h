@@ -15,6 +15,9 @@ struct DevStats {
     int error;          /* 0 or an ftn_status (NaN radiance, unsupported material) */
     int _pad;
     unsigned long long quad_records, quad_records_any;   /* four-box records fetched by the counting builds of k_wf_trace4 / k_wf_trace4_any */
+    /* lane occupancy of the counting builds of k_wf_trace4 ([0..6]) / k_wf_trace4_any ([7..13]), wave-level tallies: control rounds, record steps
+     * executed, lanes active in them, leaf steps, lanes active in them, refills, lanes re-armed (FTN_WF_DEBUG=1 prints them) */
+    unsigned long long t4_occ[14];
 };
 
 struct DTile { int x0, y0, x1, y1; unsigned long long tile_id; uint32_t valid_off, _pad; };   /* sample-space tile, its sampler seed, exclusive prefix sum of pixel counts */

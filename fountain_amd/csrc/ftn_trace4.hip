@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
     unsigned long long n_rec = 0, n_prim = 0;
+    unsigned long long occ[7] = {0, 0, 0, 0, 0, 0, 0};       /* COUNT: DevStats::t4_occ (wave-uniform values, added by lane 0) */
     T4Lane L; L.mode = T4_IDLE; L.cur = 0; L.lp = 0; L.finish = false;
     WaveQueue Q; wq_init(Q, count, chunk_max);
     uint32_t rid = 0;
@@ -202,6 +203,7 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
             const uint32_t avail = Q.chunk_end - Q.chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             bool hand_back = false; uint32_t q_entry = 0;
+            if (COUNT) { occ[5]++; occ[6] += need < avail ? need : avail; }
             if (L.mode == T4_IDLE && rank < avail) {
                 float4 a, b;
                 q_entry = queue[Q.chunk_next + rank];
@@ -220,6 +222,7 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
         const unsigned long long m_node = __ballot(L.mode == T4_NODE), m_leaf = __ballot(L.mode == T4_LEAF);
         if ((m_node | m_leaf) == 0) { if (Q.exhausted) break; else continue; }
         L.finish = false;
+        if (COUNT) occ[0]++;
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
             /* ---- record steps.  One ballot per step decides whether any lane could leave LDS during it (a step pushes at most three
              * entries): nearly never, and then its pushes and pops need no bounds checks */
@@ -227,11 +230,13 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
             for (int burst = 0; burst < BURST; burst++) {
                 const bool on = L.mode == T4_NODE && !L.finish;
                 if (COUNT && on) n_rec++;
+                if (COUNT) { const unsigned long long m_on = __ballot(on); if (m_on) { occ[1]++; occ[2] += (unsigned long long)__popcll(m_on); } }
                 if (__builtin_expect(__ballot(on && (st_tiny || St.sp > st_soft)) == 0, 1)) { if (on) t4_record_step<false>(S, R, St, L); }
                 else if (on) t4_record_step<true>(S, R, St, L);
             }
         } else {
             /* ---- leaf step: one primitive per lane */
+            if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
             if (L.mode == T4_LEAF) {
                 const uint32_t prim = L.lp;
                 float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
@@ -251,7 +256,7 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { n_rec += __shfl_down(n_rec, off, 64); n_prim += __shfl_down(n_prim, off, 64); }
-        if (lane == 0) { if (n_rec) atomicAdd(&stats->quad_records, n_rec); if (n_prim) atomicAdd(&stats->prims_tested, n_prim); }
+        if (lane == 0) { if (n_rec) atomicAdd(&stats->quad_records, n_rec); if (n_prim) atomicAdd(&stats->prims_tested, n_prim); for (int k = 0; k < 7; k++) if (occ[k]) atomicAdd(&stats->t4_occ[k], occ[k]); }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_closest, (unsigned long long)count);
 }
@@ -305,6 +310,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
     unsigned long long n_rec = 0, n_prim = 0;
+    unsigned long long occ[7] = {0, 0, 0, 0, 0, 0, 0};
     T4Lane L; L.mode = T4_IDLE; L.cur = 0; L.lp = 0; L.finish = false;
     WaveQueue Q; wq_init(Q, count, chunk_max);
     uint32_t rid = 0;
@@ -319,6 +325,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
             const uint32_t avail = Q.chunk_end - Q.chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             bool hand_back = false; uint32_t q_entry = 0;
+            if (COUNT) { occ[5]++; occ[6] += need < avail ? need : avail; }
             if (L.mode == T4_IDLE && rank < avail) {
                 float4 a, b;
                 q_entry = queue[Q.chunk_next + rank];
@@ -336,15 +343,18 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
         const unsigned long long m_node = __ballot(L.mode == T4_NODE), m_leaf = __ballot(L.mode == T4_LEAF);
         if ((m_node | m_leaf) == 0) { if (Q.exhausted) break; else continue; }
         L.finish = false;
+        if (COUNT) occ[0]++;
         if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
 #pragma unroll
             for (int burst = 0; burst < BURST; burst++) {
                 const bool on = L.mode == T4_NODE && !L.finish;
                 if (COUNT && on) n_rec++;
+                if (COUNT) { const unsigned long long m_on = __ballot(on); if (m_on) { occ[1]++; occ[2] += (unsigned long long)__popcll(m_on); } }
                 if (__builtin_expect(__ballot(on && (st_tiny || St.sp > st_soft)) == 0, 1)) { if (on) t4_any_step<false, POLICY>(S, R, St, L); }
                 else if (on) t4_any_step<true, POLICY>(S, R, St, L);
             }
         } else {
+            if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
             if (L.mode == T4_LEAF) {
                 const uint32_t prim = L.lp;
                 float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
@@ -366,6 +376,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
         if (lane == 0) {
             if (n_rec) { atomicAdd(&stats->quad_records, n_rec); atomicAdd(&stats->quad_records_any, n_rec); }
             if (n_prim) { atomicAdd(&stats->prims_tested, n_prim); atomicAdd(&stats->prims_any, n_prim); }
+            for (int k = 0; k < 7; k++) if (occ[k]) atomicAdd(&stats->t4_occ[7 + k], occ[k]);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
@@ -377,10 +388,11 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
 Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any) {
     Trace4Plan p; memset(&p, 0, sizeof(p));
     const uint32_t bound = S.quad_stack_bound ? S.quad_stack_bound : 1u;
-    /* workgroups per CU the LDS stacks should leave room for: what the kernels' registers allow (closest-hit 90-94 VGPRs -> 5 waves per
-     * SIMD -> 5 workgroups of 4 waves; any-hit 68 VGPRs -> 7), measured optimum in DESIGN.md.  2 KB of the 160 KB stay free: five
-     * workgroups of exactly 32 KB were observed to run as four. */
-    const uint32_t wg_c = knob_wg_closest ? knob_wg_closest : 5u, wg_a = knob_wg_any ? knob_wg_any : 6u;
+    /* workgroups per CU the LDS stacks should leave room for.  Closest-hit: what its registers allow (96 VGPRs -> 5 waves per SIMD -> 5
+     * workgroups of 4 waves; 4: +6 % time, 3: +23 %).  Any-hit: 4 (71 VGPRs would allow 7, but 4 measured best: 109.3 ms per step against
+     * 112.4 at 6 and 116.5 at 3 -- fewer rays in flight walk the shared upper levels closer together; profiles/r02/e_probe_wg_low.log).
+     * 2 KB of the 160 KB stay free: five workgroups of exactly 32 KB were observed to run as four. */
+    const uint32_t wg_c = knob_wg_closest ? knob_wg_closest : 5u, wg_a = knob_wg_any ? knob_wg_any : 4u;
     const uint32_t budget_c = ((158u * 1024u) / wg_c) & ~1023u, budget_a = ((158u * 1024u) / wg_a) & ~1023u;
     uint32_t ec = knob_entries_closest ? knob_entries_closest : budget_c / (256u * 8u);
     uint32_t ea = knob_entries_any ? knob_entries_any : budget_a / (256u * 4u);
