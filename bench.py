@@ -235,7 +235,7 @@ def roofline(args, cst, tot, n_steps, spp_per_step):
     r["valu_busy"] = round(dk["valu_busy"], 3) if dk.get("valu_busy") is not None else None
     r["wave_cycles_waiting_on_memory"] = round(dk["wave_cycles_waiting_on_memory"], 3) if dk.get("wave_cycles_waiting_on_memory") is not None else None
     r["binds"] = "VALU issue (valu_busy), not HBM: see DESIGN.md section 5"
-    r["traffic_source"] = "profiles/%s/traffic.json (rocprofv3 --pmc over this command, production kernels only; FETCH_SIZE x 2 + WRITE_SIZE, cross-checked with TCC_EA0_RDREQ_128B x 128 B)" % PROFILE_ROUND
+    r["traffic_source"] = "profiles/%s/traffic.json (rocprofv3 --pmc over this command, production kernels only; FETCH_SIZE x 2 + WRITE_SIZE, cross-checked with TCC_EA0_RDREQ_128B x 128 B; counted where L2 meets the fabric, so lines the 256 MB Infinity Cache serves are included: an upper bound of the DRAM bytes)" % PROFILE_ROUND
     live = {"closest": tot["trace_ms"] / n_steps, "any_hit": tot["any_ms"] / n_steps, "shade": tot["shade_ms"] / n_steps, "sort": tot["sort_ms"] / n_steps}
     groups = {}
     step_bytes = 0.0

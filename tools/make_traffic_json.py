@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["fountain_amd/csrc/ftn_trace4.hip", "fountain_amd/csrc/ftn_wavefront.hip", "fountain_amd/csrc/ftn_wf_common.h", "fountain_amd/csrc/ftn_device.h",
-           "fountain_amd/csrc/ftn_kernels.hip", "fountain_amd/csrc/ftn_host.cpp", "fountain_amd/csrc/ftn_math.h", "fountain_amd/csrc/detmath.h", "fountain_amd/csrc/ftn_texture.h"]
+           "fountain_amd/csrc/ftn_kernels.hip", "fountain_amd/csrc/ftn_kernels.h", "fountain_amd/csrc/ftn_wavefront.h", "fountain_amd/csrc/ftn_host.cpp", "fountain_amd/csrc/ftn_math.h", "fountain_amd/csrc/detmath.h", "fountain_amd/csrc/ftn_texture.h"]
 PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum"]),
           ("tcc2", ["TCC_REQ_sum", "TCC_READ_sum", "TCC_WRITE_sum", "TCC_ATOMIC_sum"]), ("tcc3", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]),
           ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY"]),
