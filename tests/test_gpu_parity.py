@@ -487,6 +487,18 @@ def test_tile_selection_cache_full_empty_full(gpu, pipeline):
     assert films[3][1]["camera_samples"] == 2 * 256 * 2
 
 
+@pytest.mark.parametrize("pipeline", [MEGA, WAVE])
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_depth_limits_zero_one_two(gpu, orc_det, pipeline, depth):
+    """max_depth 0 (emission / environment only: camera rays arrive at the depth limit), 1 and 2, on the scene with every light kind and
+    on the environment-lit cube: the depth limit travels through the active queue's entry flags (k_wf_classify), not through the path state."""
+    integ, smp = PathIntegrator(depth, 1.0), RandomSampler(2, 0, indexed=True)
+    for make, what in ((lambda be: scenes.cornell(be, res=32), "cornell"), (lambda be: scenes.rounded_cube_env(be, res=32, env_n=64), "rounded_cube_env")):
+        (rg, pg, sg), (ro, po, so) = render_pair(gpu, orc_det, make, integ, smp, pipeline)
+        assert sg["rays_closest"] == so["rays_closest"] and sg["rays_any"] == so["rays_any"]
+        assert_film_equal(pg, po, sg["spill_samples"], "%s, max_depth %d" % (what, depth))
+
+
 def test_wavefront_paths_deeper_than_255_bounces(gpu, orc_det):
     """max_depth 300, no Russian roulette, albedo-0.5 furnace: paths run the full 300 bounces; the wavefront's bounce counter used to
     be 8 bits wide.  Bit-exact against the oracle and the megakernel."""
