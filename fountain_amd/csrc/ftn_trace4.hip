@@ -51,10 +51,11 @@ __device__ inline bool slab4(float4 a, float4 b, V3 o, V3 inv, float t_max, floa
     const t4_f2 tx = (px - (t4_f2){o.x, o.x}) * (t4_f2){inv.x, inv.x};
     const t4_f2 ty = (py - (t4_f2){o.y, o.y}) * (t4_f2){inv.y, inv.y};
     const t4_f2 tz = (pz - (t4_f2){o.z, o.z}) * (t4_f2){inv.z, inv.z};
-    const t4_f2 fxy = (t4_f2){fmax_(tx.x, tx.y), fmax_(ty.x, ty.y)} * (t4_f2){k, k};
-    const float fz = fmax_(tz.x, tz.y) * k;
+    /* the reference scales every axis' far distance by k = 1 + 2 gamma(3) before taking the minimum; x -> fl(x * k) is non-decreasing
+     * (k > 0, rounding is monotone), so it commutes with min: one multiplication of the smallest far distance gives the same bits */
+    const float far_k = fmin_(fmin_(fmax_(tx.x, tx.y), fmax_(ty.x, ty.y)), fmax_(tz.x, tz.y)) * k;
     const float t0 = fmax_(fmax_(fmax_(0.0f, fmin_(tx.x, tx.y)), fmin_(ty.x, ty.y)), fmin_(tz.x, tz.y));
-    const float t1 = fmin_(fmin_(fmin_(t_max, fxy.x), fxy.y), fz);
+    const float t1 = fmin_(t_max, far_k);
     *t0o = t0; *t1o = t1;
     return !(t0 > t1);
 }
