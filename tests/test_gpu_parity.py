@@ -312,6 +312,25 @@ def test_config5_full_size(gpu, orc_det):
     assert whole.pixels[..., 3].min() >= 1.0
 
 
+@pytest.mark.parametrize("config", ["2: 64 spp", "3: 256 spp", "4-like: 1024 spp", "5: 4096 spp"])
+def test_baseline_configs_at_their_full_spp_on_a_few_tiles(gpu, orc_det, config):
+    """The other BASELINE-size tests cut the sample count; samples of a pixel are added in order, so the FULL count matters for the film
+    sums.  Here every config runs at its own spp (64 / 256 / 1024 / 4096) on a handful of tiles -- what the oracle finishes in seconds --
+    and the films and ray counts must equal the oracle's bit for bit."""
+    if config.startswith("2"):
+        make, spp, tiles, n = (lambda be: scenes.cornell(be, res=512)), 64, (5 * 32 + 9, 97, 8), 8
+    elif config.startswith("3"):
+        make, spp, tiles, n = (lambda be: scenes.rounded_cube_env(be, res=1024, env_n=512)), 256, (64 * 30 + 28, 130, 6), 6
+    elif config.startswith("4"):
+        make, spp, tiles, n = (lambda be: scenes.instanced_cubes(be, n_copies=46, res=(1920, 1080), env_n=256, lens_radius=0.4)), 1024, (120 * 30 + 55, 7, 3), 3
+    else:
+        make, spp, tiles, n = (lambda be: scenes.instanced_cubes(be, n_copies=2309, res=(4096, 4096))), 4096, (256 * 120 + 140, 517, 2), 2
+    px, st = _tile_subset_parity(gpu, orc_det, make, spp, tiles)
+    assert st["camera_samples"] == n * 256 * spp
+    # every pixel of the chosen tiles got all its samples (a jitter of exactly 0 puts a sample on two pixels, film.rs:138-139: counted as spill)
+    assert (px[..., 3] == float(spp)).sum() >= n * 256 - 4 * st["spill_samples"]
+
+
 def test_ray_queue_sort_changes_nothing(gpu, monkeypatch):
     """The wavefront pipeline sorts its secondary-ray queues for coherence; the order rays are traced in must not change
     a single bit of the film or a single counter: same render with the sort disabled."""
