@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_render_equals_whole(tmp_path, world):
     out = str(tmp_path / "merged.npz")
     port = 29500 + (os.getpid() + world) % 500
@@ -81,18 +81,20 @@ def _run(cmd, env=None, timeout=300):
     return subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
 
 
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` started plainly (no launcher environment) must start two ranks itself and report n_gpus = 2.
-    --launch-check stops after the process group has formed (no GPU here); the same code path carries the real run."""
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` started plainly (no launcher environment) must start N ranks itself and report n_gpus = N (8: the
+    round-end driver's largest job).  --launch-check stops after the process group has formed (no GPU here); the same code path
+    carries the real run."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=dict(env, OMP_NUM_THREADS="1"),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launch-check"], env=dict(env, OMP_NUM_THREADS="1"),
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout                      # stdout carries the result line alone
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["world_size_env"] == 2 and out["rank_sum"] == 1
+    assert out["n_gpus"] == n and out["world_size_env"] == n and out["rank_sum"] == n * (n - 1) // 2
 
 
 def test_bench_refuses_a_launcher_with_another_world_size():
