@@ -38,7 +38,7 @@ namespace ftn {
 
 /* pstate bits */
 /* ------------------------------------------------------------------ generate (no atomics: queue slots are known in closed form) */
-__global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W) {
+__global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W, int write_state) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;          /* path id = slot * samples + s: the samples of a pixel are neighbours */
     if (i >= W.n_paths) return;
     const uint32_t slot = i / W.samples, s = i % W.samples;
@@ -53,9 +53,14 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         DRay ray = camera_ray(P.C, p_film, p_lens, time_u);
         W.ray[2 * (size_t)(i)] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
         W.ray[2 * (size_t)(i) + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.t_max);
-        W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
-        W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
+        /* A fresh path's state is a constant (throughput 1, radiance 0) and a stream position that follows from the sample's key: the path
+         * integrator's first shading pass rebuilds it (k_wf_shade, `first`) instead of reading 64 bytes per path that this kernel would
+         * have to write.  The direct-lighting / Whitted stage still reads it. */
+        if (write_state) {
+            W.beta[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
+            W.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            W.rng01[i] = make_ulonglong2(rng.s0, rng.s1); W.rng23[i] = make_ulonglong2(rng.s2, rng.s3);
+        }
         /* (the film position is not kept: k_wf_accumulate draws it again from the sample's key) */
         /* queue order = path order: tile, pixel, sample.  A wave of the first trace (and of the first shading pass, and of the shadow
          * rays it emits) covers a few pixels instead of 64, each XCD's slice of the queue is a part of the image rather than one whole
@@ -413,7 +418,7 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
  * loads instead of one gather per field and lane) and the point / distant / area-light code is compiled out; every value computed
  * is the one the generic kernel computes for such a scene. */
 template <bool TEX, int MT, bool ENV>
-__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : (MT == 0 ? FTN_SHADE_WAVES_MATTE : FTN_SHADE_WAVES_OTHER)))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask) {
+__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : (MT == 0 ? FTN_SHADE_WAVES_MATTE : FTN_SHADE_WAVES_OTHER)))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask, uint32_t first /* 1: the pass right behind k_wf_generate -- every path is fresh */) {
     const DScene& S = P.S;
     /* virtual, 256-aligned concatenation of the selected class segments: a workgroup never straddles two classes */
     uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
@@ -441,7 +446,8 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
         uint32_t p = 0, active_entry = 0;
         if (have) {
             p = W.q_sorted[sorted_idx];
-            float4 bq = W.beta[p], lq = W.rad[p];
+            float4 bq = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE)), lq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       /* a fresh path (k_wf_generate) */
+            if (!first) { bq = W.beta[p]; lq = W.rad[p]; }
             Rgb beta(bq.x, bq.y, bq.z), L(lq.x, lq.y, lq.z);
             uint32_t ps = __float_as_uint(bq.w);
             /* ---- finish the previous bounce's estimate_direct (integrator/mod.rs:330-392) */
@@ -500,7 +506,13 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 uint32_t light_word = 0;
                 if (!hit || bounces >= P.max_depth) alive = false;
                 else {
-                    Rng rng; { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
+                    Rng rng;
+                    if (first) {      /* the stream behind the camera sample's five draws (p_film 2, p_lens 2, time 1: sampler/mod.rs:43-51), as k_wf_generate left it */
+                        const uint32_t slot = p / W.samples, sidx = p % W.samples;
+                        const DTile tile = P.tiles[slot >> 8];
+                        rng.seed(indexed_key(P.seed, tile.x0 + (int)(slot & 15u), tile.y0 + (int)((slot >> 4) & 15u), W.first_sample + sidx));
+                        (void)rng.next2(); (void)rng.next2(); (void)rng.next();
+                    } else { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
                     const int mat = si.mat;
                     if (MT == -2 || mat < 0) {
                         DRay nr = spawn_ray(si.hit, ray0.d);                       /* null bsdf: path.rs:77-81 */
@@ -1306,7 +1318,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
         const uint32_t Sp = std::min(S, total_samples - s0);
         W.n_slots = n_slots; W.samples = Sp; W.n_paths = Sp * n_slots; W.first_sample = P.first_sample + s0; W.seg_cap = (uint32_t)st->cap_paths;
         hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 0, 0, P.stats);
-        hipLaunchKernelGGL(k_wf_generate, dim3((W.n_paths + 255) / 256), dim3(256), 0, stream, P, W);
+        hipLaunchKernelGGL(k_wf_generate, dim3((W.n_paths + 255) / 256), dim3(256), 0, stream, P, W, dl_mode ? 1 : 0);
         int in_q = 0;
         const uint32_t* q_cl = W.q_closest; const uint32_t* q_sh = W.q_shadow;      /* the camera rays' queue is in pixel order already */
         /* null-material pass-throughs do not count as bounces (path.rs:77-81), so the number of rounds has no bound in max_depth alone: the
@@ -1364,15 +1376,16 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             {
                 const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));
                 const bool tex = P.S.n_textures != 0;
+                const uint32_t first = it == 0 ? 1u : 0u;
                 if (dl_mode) {
                     if (whitted) hipLaunchKernelGGL((k_wf_shade_dl<true>), sgrid, dim3(256), 0, stream, P, W, in_q);
                     else hipLaunchKernelGGL((k_wf_shade_dl<false>), sgrid, dim3(256), 0, stream, P, W, in_q);
                 } else if (!knob("FTN_SHADE_SPECIALISE", 1)) {
-                    if (tex) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
-                    else hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu);
+                    if (tex) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu, first);
+                    else hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu, first);
                 } else {   /* one launch per material type present in the scene + one for the classes without a BSDF */
                     const bool env = P.S.env_only && knob("FTN_SHADE_ENV", 1);        /* lit by one InfiniteAreaLight: the variants specialised for it */
-#define FTN_SH2(T, M, E, mask) hipLaunchKernelGGL((k_wf_shade<T, M, E>), sgrid, dim3(256), 0, stream, P, W, in_q, mask)
+#define FTN_SH2(T, M, E, mask) hipLaunchKernelGGL((k_wf_shade<T, M, E>), sgrid, dim3(256), 0, stream, P, W, in_q, mask, first)
 #define FTN_SH(M, mask) do { if (tex) { if (env) FTN_SH2(true, M, true, mask); else FTN_SH2(true, M, false, mask); } \
                              else { if (env) FTN_SH2(false, M, true, mask); else FTN_SH2(false, M, false, mask); } } while (0)
                     FTN_SH(-2, 0x83u);
