@@ -352,8 +352,11 @@ struct ParallelBvh {
  * leaf takes its pair's first slot itself (the second one is empty).  The traversal kernels (ftn_trace4.hip) test the four boxes of a
  * record in one step and never test A's and B's own boxes:
  *   - Bounds3f::intersect_test (bounds.rs:214-233) is monotone in the box -- every operation in it is a correctly rounded, monotone f32
- *     operation and a NaN (0 * inf) only ever removes a constraint -- so a ray that enters a child's box enters its parent's box, for the
- *     same or any larger t_max: skipping the parent's test changes nothing the reference would have visited;
+ *     operation -- so a ray whose plane distances are all numbers and that enters a child's box enters its parent's box, for the same
+ *     or any larger t_max: skipping the parent's test changes nothing the reference would have visited.  A NaN (0 * inf: a zero direction
+ *     component with the origin on a bounding plane) drops a constraint from ONE of the two tests, so for such rays the skip is not
+ *     exact: the kernels hand every ray with a zero / non-finite 1/d component, or overflowing plane distances, to the reference-order
+ *     kernel through the exception queue (ftn_trace4.hip, point 5; ray_is_exceptional);
  *   - the reference's visiting order (near child first by dir_is_neg[split_axis], bvh.rs:187-196) of the four grandchildren follows from
  *     the three split axes of R, A and B, which the record carries.
  * Slot layout = the 32-byte node record of ftn_device.h: {min.x, max.x, min.y, max.y} {min.z, max.z, bits(link), bits(meta)};
@@ -361,7 +364,7 @@ struct ParallelBvh {
  * leaf (its primitives run to the one flagged GF_LEAF_END in `geom`).  Slot 0's meta carries the three one-hot split axes that order
  * the visit, one per byte: byte 0 A's (orders slots 0 / 1), byte 1 R's (orders the pairs), byte 2 B's (orders slots 2 / 3) -- tested
  * against the ray's dir_is_neg bits repeated in the same bytes.  An empty slot (bit 25 of its meta, for tools) holds the box
- * x = y = [0, 0], z = [+inf, +inf], which no ray with a finite non-zero 1/d enters: the kernels need no test for it.
+ * x = y = [0, 0], z = [+inf, +inf], which no ray that passes ray_is_exceptional enters: the kernels need no test for it.
  * Returns the records in DFS order (slot order) and an upper bound of the traversal stack (entries pending at any time). */
 struct QuadBvh { std::vector<float> rec; /* 32 floats per record */ uint32_t n_records = 0, stack_bound = 0; bool ok = false; };
 static void build_quads(const std::vector<ftn_bvh_node>& nodes, QuadBvh* out) {
