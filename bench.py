@@ -38,7 +38,9 @@ def main():
     ap.add_argument("--cpu-tiles", type=int, default=int(os.environ.get("FTN_BENCH_CPU_TILES", "96")))
     ap.add_argument("--dist-backend", default=os.environ.get("FTN_BENCH_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI, one GPU per rank (the measured configuration); gloo = rehearsal of the N-rank path (see --share-gpu)")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank renders on GPU 0, films merged over gloo on the host")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank renders on GPU 0, films merged over gloo on the host (implies --dist-backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--scaling", default=os.environ.get("FTN_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="weak (default): every GPU renders --spp-per-gpu samples of its tiles per step, the job's work grows with N; strong: a step is --spp-per-gpu samples of the WHOLE film whatever N is, each GPU renders its 1/N of the tiles")
     ap.add_argument("--no-count-step", action="store_true", help="skip the untimed counting step (tools/make_traffic_json.py: every dispatch of the run then belongs to the timed steps)")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, form the process group, print the result line's n_gpus -- no rendering (CPU test of the launcher)")
     args = ap.parse_args()
@@ -60,6 +62,11 @@ def main():
     use_dist = world > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1"      # the latter: rehearse the collective path on one GPU
     if args.share_gpu:
         local_rank = 0
+        if args.dist_backend != "gloo":
+            if "--dist-backend" in sys.argv[1:] or os.environ.get("FTN_BENCH_DIST_BACKEND"):
+                print("error: --share-gpu puts every rank on GPU 0 and RCCL refuses two ranks on one device: use --dist-backend gloo", file=sys.stderr)
+                sys.exit(2)
+            args.dist_backend = "gloo"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -80,7 +87,7 @@ def main():
         return
 
     from fountain_amd import Film, PathIntegrator, RandomSampler, SamplerIntegrator, default_backend, scenes, _abi as A
-    from fountain_amd.distributed import merge_film, tile_shard
+    from fountain_amd.distributed import merge_film, rank_spread, step_samples, tile_shard
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     gpu = default_backend()
@@ -100,7 +107,7 @@ def main():
     integ = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
     dev_film = torch.zeros((film.height, film.width, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    spp_per_step = world * max(1, args.spp_per_gpu)
+    spp_per_step = step_samples(args.scaling, world, args.spp_per_gpu)
     total_spp = 4096
 
     def step(i, count=False):
@@ -141,7 +148,11 @@ def main():
         for k in tot:
             tot[k] += st[k]
     cam_samples = tot["camera_samples"]
+    torch.cuda.synchronize(dev)
+    t_render = time.perf_counter() - t0                    # this rank's K steps (host clock around its own device work)
     merge()
+    torch.cuda.synchronize(dev)
+    t_merge = time.perf_counter() - t0 - t_render          # the end-of-frame reduce as this rank saw it (includes waiting for the slowest rank)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -151,6 +162,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         rays, cam_samples = int(t[1]), int(t[2])
+    # per-rank spread: where a scaling loss comes from (a slow rank, or the reduce)
+    per_rank = rank_spread({"device_ms_per_step": tot["kernel_ms"] / max(args.steps, 1), "render_wall_ms": t_render * 1e3, "merge_ms": t_merge * 1e3},
+                           device="cpu" if host_merge else dev)
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
@@ -158,13 +172,17 @@ def main():
         out = {
             "metric": "Mrays/s (primary+secondary) at fixed spp", "value": round(mrays, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / n_steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config 5 scene: %d baked copies of rounded_cube = %d triangles (%d BVH nodes, depth %d), %dx%d film, "
                                    "PathIntegrator(max_depth 5, rr 1.0), 1024^2 env-map light; one step = %d spp over the whole film"
                                    % (args.copies, info["n_prims"], info["n_nodes"], info["max_depth"], res[0], res[1], spp_per_step),
                        "tiles": n_tiles, "tiles_per_gpu": (n_tiles + world - 1) // world, "camera_samples_per_step": cam_samples // n_steps,
                        "rays_per_step": rays // n_steps, "pipeline": "wavefront", "sampler": "indexed xoshiro256+",
-                       "per_gpu_workload": per_gpu_workload(args), "scene_build_s": round(build_s, 1), "device_ms_per_step": round(tot["kernel_ms"] / n_steps, 3)},
+                       "per_gpu_workload": per_gpu_workload(args), "scene_build_s": round(build_s, 1), "device_ms_per_step": round(tot["kernel_ms"] / n_steps, 3),
+                       "device_bytes": {k: v for k, v in info.items() if k.endswith("_bytes")}},
+            # min / max over the ranks: device time of one step (HIP events inside the library), wall time of the K steps, and the single film
+            # reduce at the end of the timed region (as each rank saw it: it includes waiting for the slowest rank)
+            "ranks": {k: {"min": round(v["min"], 3), "max": round(v["max"], 3)} for k, v in per_rank.items()},
             "roofline": roofline(args, cst, tot, n_steps, spp_per_step),
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -175,6 +193,9 @@ def main():
 
 
 def per_gpu_workload(args):
+    """what ONE GPU renders per step (the PMC profile under profiles/ is of exactly this share)"""
+    if args.scaling == "strong" and args.gpus > 1:
+        return "copies=%d,res=%d,spp=%d,tiles=1/%d" % (args.copies, args.res, max(1, args.spp_per_gpu), args.gpus)
     return "copies=%d,res=%d,spp_per_gpu=%d" % (args.copies, args.res, max(1, args.spp_per_gpu))
 
 
@@ -192,7 +213,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -234,7 +255,17 @@ def roofline(args, cst, tot, n_steps, spp_per_step):
     r["l2_hit_rate"] = round(dk["l2_hit_rate"], 3)
     r["valu_busy"] = round(dk["valu_busy"], 3) if dk.get("valu_busy") is not None else None
     r["wave_cycles_waiting_on_memory"] = round(dk["wave_cycles_waiting_on_memory"], 3) if dk.get("wave_cycles_waiting_on_memory") is not None else None
-    r["binds"] = "VALU issue (valu_busy), not HBM: see DESIGN.md section 5"
+    # the roof that binds: VALU issue slots x lane utilisation.  valu_busy = the fraction of the launch's SIMD cycles in which a VALU instruction
+    # issues (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)); lanes_per_valu_inst = the lanes live in the average VALU instruction
+    # (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU); their product / 64 is the fraction of the chip's lane-issue slots that do work
+    if dk.get("valu_busy") is not None and dk.get("lanes_per_valu_inst") is not None:
+        r["issue"] = {"valu_busy": round(dk["valu_busy"], 3), "lanes_per_valu_inst": round(dk["lanes_per_valu_inst"], 1), "of_lanes": 64,
+                      "frac": round(dk["valu_busy"] * dk["lanes_per_valu_inst"] / 64.0, 4)}
+        r["bound"] = "valu_issue" if dk["valu_busy"] > (r["frac"] or 0.0) else "hbm"
+    r["hbm"] = {"achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"], "traffic": r["traffic"]}
+    r["binds"] = ("VALU issue: the kernel issues a VALU instruction in %.0f %% of its SIMD cycles with %.0f of 64 lanes live; the HBM interface runs at %.0f %% of its peak "
+                  "(achieved / peak / frac / traffic are the HBM figures the bench contract asks for; `issue` is the binding roof)"
+                  % (100.0 * (dk.get("valu_busy") or 0.0), dk.get("lanes_per_valu_inst") or 0.0, 100.0 * (r["frac"] or 0.0)))
     r["traffic_source"] = "profiles/%s/traffic.json (rocprofv3 --pmc over this command, production kernels only; FETCH_SIZE x 2 + WRITE_SIZE, cross-checked with TCC_EA0_RDREQ_128B x 128 B; counted where L2 meets the fabric, so lines the 256 MB Infinity Cache serves are included: an upper bound of the DRAM bytes)" % PROFILE_ROUND
     live = {"closest": tot["trace_ms"] / n_steps, "any_hit": tot["any_ms"] / n_steps, "shade": tot["shade_ms"] / n_steps, "sort": tot["sort_ms"] / n_steps}
     groups = {}
@@ -245,8 +276,16 @@ def roofline(args, cst, tot, n_steps, spp_per_step):
         groups[g] = {"ms_per_step": round(ms, 2) if ms is not None else None, "hbm_GB_per_step": round(v["hbm_bytes_per_step"] / 1e9, 2),
                      "hbm_frac": round(v["hbm_bytes_per_step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None, "l2_hit_rate": round(v["l2_hit_rate"], 3),
                      "valu_busy": round(v["valu_busy"], 3) if v.get("valu_busy") is not None else None}
-    r["groups"] = groups
     step_ms = tot["kernel_ms"] / n_steps
+    if "other" in groups and groups["other"]["ms_per_step"] is None:        # generate / accumulate / resets: what the four timed groups leave of the step's device time
+        oms = max(step_ms - sum(v for v in live.values()), 0.0)
+        groups["other"]["ms_per_step"] = round(oms, 2)
+        groups["other"]["hbm_frac"] = round(tj["groups"]["other"]["hbm_bytes_per_step"] / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if oms > 0 else None
+    if cst is not None and "shade" in groups:
+        events = cst["rays_closest"] - cst["mis_rays_any_hit"]              # every ray of a closest-hit launch is classified and shaded once
+        groups["shade"]["shading_events_per_step"] = int(events)
+        groups["shade"]["hbm_bytes_per_event"] = round(tj["groups"]["shade"]["hbm_bytes_per_step"] / max(events, 1), 1)
+    r["groups"] = groups
     r["whole_step"] = {"device_ms": round(step_ms, 2), "hbm_GB": round(step_bytes / 1e9, 1), "hbm_frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_ms > 0 else None}
     return r
 

@@ -48,6 +48,10 @@ class Backend:
         self.is_oracle = is_oracle
         le = getattr(self.lib, prefix + "last_error")
         le.restype = C.c_char_p
+        if not is_oracle:                     # the structs below are read and written by the library: a build against another header is refused here
+            have = self.lib.ftn_abi_version() if hasattr(self.lib, "ftn_abi_version") else 0
+            if have != A.FTN_ABI_VERSION:
+                raise FountainError(A.FTN_ERR_INTERNAL, "%s reports ABI version %d, this binding was written for %d: rebuild the library" % (path, have, A.FTN_ABI_VERSION))
         for name in ("transform_scale", "transform_rotate", "transform_perspective", "sphere_init", "camera_perspective"):
             fn = getattr(self.lib, prefix + name)
             if name == "transform_scale":
@@ -701,8 +705,13 @@ class Scene:
         nn, npr, nl, md = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         wb = (C.c_float * 6)()
         self.be.call("scene_info", self.handle, C.byref(nn), C.byref(npr), C.byref(nl), C.byref(md), wb)
-        return dict(n_nodes=nn.value, n_prims=npr.value, n_lights=nl.value, max_depth=md.value,
-                    world_bound=np.array(wb[:], dtype=np.float32))
+        out = dict(n_nodes=nn.value, n_prims=npr.value, n_lights=nl.value, max_depth=md.value,
+                   world_bound=np.array(wb[:], dtype=np.float32))
+        if not self.be.is_oracle:             # device bytes per array (ftn_scene_memory_info)
+            m = A.ftn_scene_memory()
+            self.be.call("scene_memory_info", self.handle, C.byref(m))
+            out.update({k + "_bytes": int(getattr(m, k)) for k, _ in m._fields_})
+        return out
 
     def nodes(self):
         i = self.info()

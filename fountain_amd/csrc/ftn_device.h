@@ -29,6 +29,11 @@ namespace ftn {
 
 #define FTN_DEV_NOINLINE __device__ inline   /* out-of-line variants were measured slower (see detmath.h) */
 
+/* float4s per primitive in DScene::geom: 4 = one 64-byte half line per primitive (a 48-byte record at stride 48 straddles two 128-byte
+ * lines one time in three, and a leaf test is a random fetch: 1.33 lines instead of 1) */
+#ifndef FTN_GS
+#define FTN_GS 3
+#endif
 enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u, GF_LEAF_END = 16u /* last primitive of its BVH leaf */, GF_HAS_TANGENTS = 32u /* per-vertex shading tangents in DScene::T */ };
 enum : uint32_t { LK_POINT = 0, LK_DISTANT = 1, LK_INFINITE = 2, LK_AREA = 3 };
 
@@ -210,11 +215,27 @@ __device__ inline bool tri_hit(V3 o, V3 d, float t_max, V3 p0, V3 p1, V3 p2, flo
     *t_out = t; *b0o = b0; *b1o = b1; *b2o = b2;
     return true;
 }
+/* Per-primitive attributes.  A scene with shading records (DScene::srec, the default) keeps everything below in the primitive's own
+ * 128-byte record and does not carry prim_info / N / UV on the device at all (they are the same values gathered through the vertex indices:
+ * 560 MB at 10 M triangles); without records (FTN_SREC=0) or for meshes with shading tangents the indexed arrays are resident. */
+__device__ inline void prim_mat_light(const DScene& S, int prim, int* mat, int* light) {
+    if (S.srec) { const float4* R = S.srec + 8 * (size_t)prim; *mat = (int)__float_as_uint(R[1].w); *light = (int)__float_as_uint(R[2].w); }
+    else { const uint4 pi = S.prim_info[2 * prim]; *mat = (int)pi.x; *light = (int)pi.y; }
+}
+__device__ inline void prim_normals(const DScene& S, int prim, V3* n0, V3* n1, V3* n2) {
+    if (S.srec) { const float4* R = S.srec + 8 * (size_t)prim; const float4 r3 = R[3], r4 = R[4], r5 = R[5]; *n0 = V3(r3.x, r3.y, r3.z); *n1 = V3(r4.x, r4.y, r4.z); *n2 = V3(r5.x, r5.y, r5.z); }
+    else { const uint4 vi = S.prim_info[2 * prim + 1]; const float* N = S.N;
+           *n0 = V3(N[3 * vi.x], N[3 * vi.x + 1], N[3 * vi.x + 2]); *n1 = V3(N[3 * vi.y], N[3 * vi.y + 1], N[3 * vi.y + 2]); *n2 = V3(N[3 * vi.z], N[3 * vi.z + 1], N[3 * vi.z + 2]); }
+}
+__device__ inline void prim_uvs(const DScene& S, int prim, float* u0x, float* u0y, float* u1x, float* u1y, float* u2x, float* u2y) {
+    if (S.srec) { const float4* R = S.srec + 8 * (size_t)prim; const float4 r6 = R[6]; *u0x = R[3].w; *u0y = R[4].w; *u1x = R[5].w; *u1y = r6.x; *u2x = r6.y; *u2y = r6.z; }
+    else { const uint4 vi = S.prim_info[2 * prim + 1]; const float* UV = S.UV;
+           *u0x = UV[2 * vi.x]; *u0y = UV[2 * vi.x + 1]; *u1x = UV[2 * vi.y]; *u1y = UV[2 * vi.y + 1]; *u2x = UV[2 * vi.z]; *u2y = UV[2 * vi.z + 1]; }
+}
 /* the late `None` of triangle.rs:279-286: degenerate uvs AND a zero-area triangle */
 __device__ inline bool tri_uv_degenerate_reject(const DScene& S, int prim, V3 p0, V3 p1, V3 p2) {
-    uint4 vi = S.prim_info[2 * prim + 1];
-    const float* UV = S.UV;
-    float u0x = UV[2 * vi.x], u0y = UV[2 * vi.x + 1], u1x = UV[2 * vi.y], u1y = UV[2 * vi.y + 1], u2x = UV[2 * vi.z], u2y = UV[2 * vi.z + 1];
+    float u0x, u0y, u1x, u1y, u2x, u2y;
+    prim_uvs(S, prim, &u0x, &u0y, &u1x, &u1y, &u2x, &u2y);
     float determinant = (u0x - u2x) * (u1y - u2y) - (u0y - u2y) * (u1x - u2x);
     if (!(fabsf(determinant) < 1.0e-8f)) return false;
     V3 ng = cross(p2 - p0, p1 - p0);
@@ -322,7 +343,7 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
                 const uint32_t n = meta & 0xffffu;
                 for (uint32_t i = 0; i < n; i++) {
                     const uint32_t prim = idx + i;
-                    float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                    float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
                     pin4(g0); pin4(g1); pin4(g2);
                     if (COUNT) tc->prims++;
                     const uint32_t fl = __float_as_uint(g0.w);
@@ -355,7 +376,7 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
 
 /* ------------------------------------------------------------------ shading geometry from a compact hit */
 __device__ inline void load_tri(const DScene& S, int prim, V3* p0, V3* p1, V3* p2, uint32_t* flags) {
-    const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+    const float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
     *p0 = V3(g0.x, g0.y, g0.z); *p1 = V3(g1.x, g1.y, g1.z); *p2 = V3(g2.x, g2.y, g2.z); *flags = __float_as_uint(g0.w);
 }
 /* triangle.rs:270-393 */
@@ -457,13 +478,12 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
     si->hit.n = n; si->shading_n = sn; si->prim = h.prim;
 }
 __device__ inline bool make_interaction(const DScene& S, const DHit& h, const DRay& ray_before_hit, DSI* si, DSIX* ex = nullptr) {
-    const float4 g0 = S.srec ? S.srec[8 * (size_t)h.prim] : S.geom[3 * h.prim];
+    const float4 g0 = S.srec ? S.srec[8 * (size_t)h.prim] : S.geom[FTN_GS * h.prim];
     if (__float_as_uint(g0.w) & GF_KIND_SPHERE) {
         DRay r = ray_before_hit; r.t_max = FTN_INF;   /* same root selection as at traversal time */
-        float t; const float4 g1 = S.geom[3 * h.prim + 1];
+        float t; const float4 g1 = S.geom[FTN_GS * h.prim + 1];
         bool ok = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, si, ex);
-        const uint4 pi = S.prim_info[2 * h.prim];
-        si->prim = h.prim; si->mat = (int)pi.x; si->light = (int)pi.y;
+        si->prim = h.prim; prim_mat_light(S, h.prim, &si->mat, &si->light);
         return ok;
     }
     tri_interaction(S, h, ray_before_hit.d, ray_before_hit.time, si, ex, ray_before_hit.o);
@@ -472,7 +492,7 @@ __device__ inline bool make_interaction(const DScene& S, const DHit& h, const DR
 
 /* ------------------------------------------------------------------ shapes as emitters: shapes/mod.rs:39-66 */
 FTN_DEV_NOINLINE DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
-    const float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+    const float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
     const uint32_t fl = __float_as_uint(g0.w);
     DSurfHit h;
     if (fl & GF_KIND_SPHERE) {                                   /* sphere.rs:202-218 */
@@ -493,8 +513,7 @@ FTN_DEV_NOINLINE DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
     V3 n = normalize(cross(p1 - p0, p2 - p0));
     V3 sn;
     if (fl & GF_HAS_NORMALS) {
-        const uint4 vi = S.prim_info[2 * prim + 1]; const float* N = S.N;
-        V3 n0(N[3 * vi.x], N[3 * vi.x + 1], N[3 * vi.x + 2]), n1(N[3 * vi.y], N[3 * vi.y + 1], N[3 * vi.y + 2]), n2(N[3 * vi.z], N[3 * vi.z + 1], N[3 * vi.z + 2]);
+        V3 n0, n1, n2; prim_normals(S, prim, &n0, &n1, &n2);
         V3 ns = normalize(b.x * n0 + b.y * n1 + bz * n2);
         sn = faceforward(n, ns);
     } else if (fl & GF_FLIP) sn = n * -1.0f;
@@ -506,10 +525,10 @@ FTN_DEV_NOINLINE DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
 /* Shape::pdf_from_ref: intersects the light's own shape, bypassing the BVH (shapes/mod.rs:55-66) */
 FTN_DEV_NOINLINE float shape_pdf_from_ref(const DScene& S, int prim, float area, const DSurfHit& ref, V3 wi) {
     DRay ray = spawn_ray(ref, wi);
-    const float4 g0 = S.geom[3 * prim];
+    const float4 g0 = S.geom[FTN_GS * prim];
     V3 hp, hn;
     if (__float_as_uint(g0.w) & GF_KIND_SPHERE) {
-        DSI si; float t; const float4 g1 = S.geom[3 * prim + 1];
+        DSI si; float t; const float4 g1 = S.geom[FTN_GS * prim + 1];
         if (!sphere_intersect(S.spheres[__float_as_uint(g1.w)], ray, &t, &si)) return 0.0f;
         hp = si.hit.p; hn = si.hit.n;
     } else {

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <sched.h>
 #include <atomic>
 #include <limits>
 #include <functional>
@@ -421,6 +422,17 @@ static void build_quads(const std::vector<ftn_bvh_node>& nodes, QuadBvh* out) {
     out->ok = true;
 }
 
+static int bvh_default_threads() {
+    int cores = (int)std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) cores = c; }
+#endif
+    int ranks = 1;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int r = atoi(e); if (r > 1) ranks = r; }
+    return std::max(1, cores / ranks);
+}
+
 struct HostScene {
     std::vector<ftn_bvh_node> nodes; std::vector<uint32_t> order; uint32_t max_depth = 0; Aabb world;
     std::vector<int32_t> light_kind, light_prim;
@@ -495,7 +507,9 @@ static int build_host_scene(const ftn_scene_desc* d, HostScene* hs) {
     hs->world = aabb_empty();
     if (d->n_prims) {
         BvhBuilder b(pb);
-        int n_threads = (int)std::thread::hardware_concurrency();
+        /* build threads: this process's share of the host -- the cores it may run on (affinity mask), divided by the ranks a launcher
+         * started on this node (LOCAL_WORLD_SIZE: an 8-rank job builds eight scenes side by side), at most 32; FTN_BVH_THREADS overrides */
+        int n_threads = bvh_default_threads();
         if (const char* e = getenv("FTN_BVH_THREADS")) n_threads = atoi(e);
         if (n_threads > 32) n_threads = 32;
         if (n_threads > 1 && d->n_prims >= (1u << 16)) {
@@ -643,14 +657,19 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     }
     /* two-box records (see DScene::fat): one per interior node, numbered in DFS order */
     if (hs.nodes.size() >= (1u << 27)) return fail(FTN_ERR_UNSUPPORTED, "more than 2^27 BVH nodes (node links are 32-bit byte offsets)");
-    std::vector<uint32_t> fat_id(hs.nodes.size(), 0xffffffffu);
+    /* only the legacy any-hit kernel (k_wf_trace_any2: FTN_TRACE4=0, or a scene without four-box records) reads them: 639 MB at 10 M
+     * triangles that a default scene does not allocate.  A scene created without them still renders under FTN_TRACE4=0 (plain node walk). */
+    auto env_is = [](const char* name, int value) { const char* v = getenv(name); return v && atoi(v) == value; };
+    const bool want_fat = env_is("FTN_TRACE4", 0) || env_is("FTN_QUAD", 0) || env_is("FTN_FAT", 1);
+    std::vector<uint32_t> fat_id(want_fat ? hs.nodes.size() : 0, 0xffffffffu);
     uint32_t n_fat = 0;
-    for (size_t i = 0; i < hs.nodes.size(); i++) if (!hs.nodes[i].is_leaf) fat_id[i] = n_fat++;
+    if (want_fat) for (size_t i = 0; i < hs.nodes.size(); i++) if (!hs.nodes[i].is_leaf) fat_id[i] = n_fat++;
     std::vector<float4> fat(4 * (size_t)n_fat);
     std::vector<uint8_t> leaf_end(np, 0);
     for (size_t i = 0; i < hs.nodes.size(); i++) {
         const ftn_bvh_node& n = hs.nodes[i];
         if (n.is_leaf) { if (n.n_prims) leaf_end[n.idx + n.n_prims - 1] = 1; continue; }
+        if (!want_fat) continue;
         const size_t ch[2] = {i + 1, (size_t)n.idx};
         for (int k = 0; k < 2; k++) {                            /* the two children's node records side by side (same layout as `nodes`) */
             const ftn_bvh_node& c = hs.nodes[ch[k]];
@@ -662,13 +681,13 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     }
     std::vector<int> prim_light(np, -1);
     for (size_t l = 0; l < hs.light_prim.size(); l++) if (hs.light_prim[l] >= 0) prim_light[hs.light_prim[l]] = (int)l;
-    std::vector<float4> geom(3 * np); std::vector<uint4> info(2 * np);
+    std::vector<float4> geom((size_t)FTN_GS * np); std::vector<uint4> info(2 * np);
     for (size_t i = 0; i < np; i++) {
         const ftn_prim& p = d->prims[hs.order[i]];
         uint32_t fl = 0;
         if (p.shape_kind == FTN_SHAPE_SPHERE) {
             fl = GF_KIND_SPHERE | (leaf_end[i] ? GF_LEAF_END : 0u);
-            geom[3 * i] = make_float4(0, 0, 0, ftn_det::u2f(fl)); geom[3 * i + 1] = make_float4(0, 0, 0, ftn_det::u2f(p.shape_index)); geom[3 * i + 2] = make_float4(0, 0, 0, 0);
+            geom[FTN_GS * i] = make_float4(0, 0, 0, ftn_det::u2f(fl)); geom[FTN_GS * i + 1] = make_float4(0, 0, 0, ftn_det::u2f(p.shape_index)); geom[FTN_GS * i + 2] = make_float4(0, 0, 0, 0);
             info[2 * i + 1] = make_uint4(0, 0, 0, p.shape_index);
         } else {
             const ftn_mesh& m = d->meshes[d->tri_mesh[p.shape_index]];
@@ -679,9 +698,9 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if (leaf_end[i]) fl |= GF_LEAF_END;
             const uint32_t* vi = d->tri_indices + 3 * (size_t)p.shape_index;
             const float* P = d->P;
-            geom[3 * i] = make_float4(P[3 * vi[0]], P[3 * vi[0] + 1], P[3 * vi[0] + 2], ftn_det::u2f(fl));
-            geom[3 * i + 1] = make_float4(P[3 * vi[1]], P[3 * vi[1] + 1], P[3 * vi[1] + 2], ftn_det::u2f(p.shape_index));
-            geom[3 * i + 2] = make_float4(P[3 * vi[2]], P[3 * vi[2] + 1], P[3 * vi[2] + 2], 0.0f);
+            geom[FTN_GS * i] = make_float4(P[3 * vi[0]], P[3 * vi[0] + 1], P[3 * vi[0] + 2], ftn_det::u2f(fl));
+            geom[FTN_GS * i + 1] = make_float4(P[3 * vi[1]], P[3 * vi[1] + 1], P[3 * vi[1] + 2], ftn_det::u2f(p.shape_index));
+            geom[FTN_GS * i + 2] = make_float4(P[3 * vi[2]], P[3 * vi[2] + 1], P[3 * vi[2] + 2], 0.0f);
             info[2 * i + 1] = make_uint4(vi[0], vi[1], vi[2], p.shape_index);
         }
         info[2 * i] = make_uint4((uint32_t)p.material, (uint32_t)prim_light[i], fl, 0);
@@ -690,8 +709,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     if ((rc = sc->nodes.upload(nodes.data(), nodes.size()))) return rc;
     if ((rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
     /* two-box record links are 31-bit byte offsets: beyond 2^25 interior nodes the any-hit kernel falls back to the plain node walk */
-    if (n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
-    if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
+    if (n_fat && n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
     /* four-box records (DScene::quad): what the production traversal kernels walk.  FTN_QUAD=0: not built (the two-record kernels run) */
     uint32_t n_quads = 0, quad_bound = 0;
     {
@@ -712,7 +730,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             for (size_t i = 0; i < np; i++) {
                 float4* R = &rec[8 * i];
                 const uint4 pi = info[2 * i], vi = info[2 * i + 1];
-                R[0] = geom[3 * i]; R[1] = geom[3 * i + 1]; R[2] = geom[3 * i + 2];
+                R[0] = geom[FTN_GS * i]; R[1] = geom[FTN_GS * i + 1]; R[2] = geom[FTN_GS * i + 2];
                 R[1].w = ftn_det::u2f(pi.x); R[2].w = ftn_det::u2f(pi.y); R[6].w = ftn_det::u2f(vi.w);
                 const uint32_t fl = ftn_det::f2u(R[0].w);
                 if (fl & GF_KIND_SPHERE) continue;
@@ -726,9 +744,16 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if ((rc = sc->srec.upload(rec.data(), rec.size()))) return rc;
         }
     }
-    if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
-    if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
-    if (d->S && (rc = sc->T.upload(d->S, 3 * (size_t)d->n_vertices))) return rc;
+    /* prim_info and the per-vertex normals / uvs: what the shading records replace (ftn_device.h: prim_mat_light / prim_normals / prim_uvs).
+     * Resident only without records, or when a mesh has shading tangents (gathered through prim_info's vertex indices) */
+    bool any_tangents = false;
+    for (uint32_t i = 0; i < d->n_meshes; i++) if (d->meshes[i].has_tangents && d->S) any_tangents = true;
+    if (!sc->srec.p || any_tangents || env_is("FTN_LEGACY_ARRAYS", 1)) {
+        if ((rc = sc->prim_info.upload(info.data(), info.size()))) return rc;
+        if (d->N && (rc = sc->N.upload(d->N, 3 * (size_t)d->n_vertices))) return rc;
+        if (d->UV && (rc = sc->UV.upload(d->UV, 2 * (size_t)d->n_vertices))) return rc;
+    }
+    if (any_tangents && (rc = sc->T.upload(d->S, 3 * (size_t)d->n_vertices))) return rc;
     std::vector<DSphere> sph(d->n_spheres);
     for (uint32_t i = 0; i < d->n_spheres; i++) {
         const ftn_sphere& s = d->spheres[i]; DSphere& o = sph[i];
@@ -890,7 +915,8 @@ static int set_device(int device) {
 extern "C" {
 
 const char* ftn_last_error(void) { return g_err.c_str(); }
-const char* ftn_version(void) { return "fountain_hip 0.1 (gfx950)"; }
+const char* ftn_version(void) { return "fountain_hip 0.3 (gfx950)"; }
+int ftn_abi_version(void) { return FTN_ABI_VERSION; }
 int ftn_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 int ftn_bvh_build(const ftn_scene_desc* d, ftn_bvh_node* nodes_out, uint32_t* order_out, uint32_t* n_nodes_out, uint32_t* max_depth_out) {
@@ -932,6 +958,20 @@ int ftn_scene_info(const ftn_scene* s, uint32_t* n_nodes, uint32_t* n_prims, uin
     if (n_lights) *n_lights = (uint32_t)s->host.light_kind.size();
     if (max_depth) *max_depth = s->host.max_depth;
     if (wb) for (int i = 0; i < 3; i++) { wb[i] = s->host.world.lo[i]; wb[3 + i] = s->host.world.hi[i]; }
+    return FTN_OK;
+}
+int ftn_scene_memory_info(const ftn_scene* s, ftn_scene_memory* m) {
+    if (!s || !m) return fail(FTN_ERR_INVALID_ARGUMENT, "null scene / output");
+    memset(m, 0, sizeof(*m));
+    m->nodes = s->nodes.n * sizeof(float4); m->quad = s->quad.n * sizeof(float4); m->fat = s->fat.n * sizeof(float4); m->geom = s->geom.n * sizeof(float4);
+    m->srec = s->srec.n * sizeof(float4); m->indexed_attributes = s->prim_info.n * sizeof(uint4) + (s->N.n + s->UV.n + s->T.n) * sizeof(float);
+    m->prim_class = s->prim_class.n;
+    m->lights = s->lights.n * sizeof(DLight) + s->inf_lights.n * sizeof(uint32_t);
+    for (const auto& b : s->misc) m->lights += b.n * sizeof(float);
+    for (const auto& b : s->misc4) m->lights += b.n * sizeof(float4);
+    m->textures = s->textures.n * sizeof(ftn_texture) + s->mtex.n * sizeof(ftn_material_textures) + s->images.n * sizeof(DImage) + s->texels.n * sizeof(float4);
+    m->other = s->spheres.n * sizeof(DSphere) + s->materials.n * sizeof(ftn_material) + s->stats.n * sizeof(DevStats);
+    m->total = m->nodes + m->quad + m->fat + m->geom + m->srec + m->indexed_attributes + m->prim_class + m->lights + m->textures + m->other;
     return FTN_OK;
 }
 int ftn_scene_get_nodes(const ftn_scene* s, ftn_bvh_node* nodes, uint32_t* order) {

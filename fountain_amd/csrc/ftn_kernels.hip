@@ -85,8 +85,8 @@ __device__ inline Rgb estimate_direct(Tracer<COUNT>& T, const DBsdf& B, const DS
             const DRay ray0 = ray;
             DHit h; Rgb inc(0.0f);
             if (T.closest(ray, &h)) {
-                const uint4 pi = S.prim_info[2 * h.prim];
-                if ((int)pi.y >= 0 && (int)pi.y == light_index) {          /* the hit primitive's area light is THIS light (:370-381) */
+                int h_mat, h_light; prim_mat_light(S, h.prim, &h_mat, &h_light);
+                if (h_light >= 0 && h_light == light_index) {          /* the hit primitive's area light is THIS light (:370-381) */
                     DSI s2; make_interaction(S, h, ray0, &s2);
                     inc = area_Le(L, s2.hit.n, -sc.wi);              /* si.emitted_radiance(-scatter.wi) */
                 }

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
             if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
             if (L.mode == T4_LEAF) {
                 const uint32_t prim = L.lp;
-                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) n_prim++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
             if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
             if (L.mode == T4_LEAF) {
                 const uint32_t prim = L.lp;
-                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) n_prim++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any_dual(DScene S, WfBuffers 
             if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(__ballot(t4s_mode(P) == T4_LEAF)); }
             if (t4s_mode(P) == T4_LEAF) {
                 const uint32_t prim = P.pos;
-                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) n_prim++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             if (COUNT) w_leaf_steps++;
             if (mode == TM_LEAF) {
                 const uint32_t prim = lp;
-                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) tc.prims++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
         } else {
             if (mode == TM_LEAF) {
                 const uint32_t prim = lp;
-                float4 g0 = S.geom[3 * prim], g1 = S.geom[3 * prim + 1], g2 = S.geom[3 * prim + 2];
+                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 const bool hh = prim_hit<SPHERES>(S, prim, g0, g1, g2, o, dorig, t_max, kz, sx, sy, sz, &t, &b0, &b1, &b2);
@@ -470,8 +470,8 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                     Rgb inc(0.0f);
                     if (mh.prim >= 0) {
                       if (!ENV) {                                /* ENV: no primitive carries an area light */
-                        const uint4 pi = S.prim_info[2 * mh.prim];
-                        if ((int)pi.y >= 0 && (int)pi.y == light_index) {
+                        int h_mat, h_light; prim_mat_light(S, mh.prim, &h_mat, &h_light);
+                        if (h_light >= 0 && h_light == light_index) {
                             DRay r0; r0.o = V3(mo.x, mo.y, mo.z); r0.d = V3(md.x, md.y, md.z); r0.t_max = FTN_INF; r0.time = 0.0f;
                             DSI s2; make_interaction(S, mh, r0, &s2);
                             inc = area_Le(Lt, s2.hit.n, -r0.d);
@@ -713,8 +713,8 @@ __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W
                         const float4 mo = W.ray[2 * (size_t)(p + W.n_paths)], md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
                         Rgb inc(0.0f);
                         if (mh.prim >= 0) {
-                            const uint4 pi = S.prim_info[2 * mh.prim];
-                            if ((int)pi.y >= 0 && (int)pi.y == light_index) {
+                            int h_mat, h_light; prim_mat_light(S, mh.prim, &h_mat, &h_light);
+                            if (h_light >= 0 && h_light == light_index) {
                                 DRay r0; r0.o = V3(mo.x, mo.y, mo.z); r0.d = V3(md.x, md.y, md.z); r0.t_max = FTN_INF; r0.time = 0.0f;
                                 DSI s2; make_interaction(S, mh, r0, &s2);
                                 inc = area_Le(Lt, s2.hit.n, -r0.d);
@@ -1321,6 +1321,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     /* HIP events around a group of launches on the stream they are launched on */
     auto span_begin = [&](hipStream_t sm) -> int { const int a = ev_used++; (void)hipEventRecord(st->ev[a], sm); return a; };
     auto span_end = [&](int a, int kind, hipStream_t sm) { const int b = ev_used++; (void)hipEventRecord(st->ev[b], sm); spans.push_back(Span{a, b, kind}); };
+    /* (a lambda: whatever way it is left -- an error in the middle of a bounce included -- the recorded spans are collected below) */
+    auto render_passes = [&]() -> int {
     for (uint32_t s0 = 0; s0 < total_samples; s0 += S) {
         const uint32_t Sp = std::min(S, total_samples - s0);
         W.n_slots = n_slots; W.samples = Sp; W.n_paths = Sp * n_slots; W.first_sample = P.first_sample + s0; W.seg_cap = (uint32_t)st->cap_paths;
@@ -1334,7 +1336,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
         for (uint32_t it = 0; it < max_iter; it++) {
             bool polled = false;
             const unsigned tg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
-            if (ev_used + 8 > 64) { rc = flush_events(); if (rc) return rc; }
+            if (ev_used + 10 > 64) { rc = flush_events(); if (rc) return rc; }
             /* The two traces of a bounce are independent (own queues, own result arrays).  A persistent traversal kernel ends with a
              * long drain -- the last rays are sequential walks of several hundred nodes while most waves have already left (measured:
              * 0.3-0.8 ms from the first idle wave to the end of every launch) -- so the any-hit launch goes to a second stream and its
@@ -1372,13 +1374,17 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 span_end(e, 1, as);
                 if (beside) WF_TRY(hipEventRecord(st->ev_side, st->side));
             }
-            const int e_shade = span_begin(stream);
             {   /* group the active paths by shading class (reads the hit records the traces just wrote) */
+                const int e_cls = span_begin(stream);
                 const unsigned cg = std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256);
                 hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
                 hipLaunchKernelGGL(k_wf_classify, dim3(cg), dim3(256), 0, stream, P, W, in_q);
+                span_end(e_cls, 2, stream);
             }
-            if (beside) WF_TRY(hipStreamWaitEvent(stream, st->ev_side, 0));     /* shading needs the occlusion results (classify above did not) */
+            /* shading needs the occlusion results (classify above did not).  The shade span starts BEHIND this wait: with the any-hit launch
+             * on the side stream the wait is any-hit time, which has its own span */
+            if (beside) WF_TRY(hipStreamWaitEvent(stream, st->ev_side, 0));
+            const int e_shade = span_begin(stream);
             hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
             {
                 const dim3 sgrid(std::min<unsigned>(shade_grid_max, (W.n_paths + 255) / 256));
@@ -1437,7 +1443,11 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
         if (W.mis_any) mis_any_rays += st->host_counters[CTR(10)];   /* the last poll of the pass saw the pass's total */
         hipLaunchKernelGGL(k_wf_accumulate, dim3((n_slots + 255) / 256), dim3(256), 0, stream, P, W);
     }
-    rc = flush_events(); if (rc) return rc;
+    return FTN_OK;
+    };
+    rc = render_passes();
+    { const int rc_flush = flush_events(); if (!rc) rc = rc_flush; }
+    if (rc) return rc;
     WF_TRY(hipGetLastError());
     if (times) {
         times->trace_ms = trace_ms; times->trace_launches = trace_launches; times->mis_any_rays = mis_any_rays;

@@ -7,9 +7,11 @@
     GPU must never be replaced by another program on this pool), relays their output and exits with the launcher's code.
 This module imports neither torch nor the HIP library."""
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 
 
 def world_from_env():
@@ -27,11 +29,32 @@ def free_port():
     return port
 
 
+def _stop(proc, grace=5.0):
+    """Ends the launcher AND its ranks: SIGTERM to the launcher (torch.distributed.run forwards it to its workers and reaps them), a few
+    seconds of grace, then SIGKILL to the whole process group the launcher was started in (start_new_session: the ranks are in it) --
+    a SIGKILL to the launcher alone cannot be handled and would leave the ranks running with their GPUs."""
+    if proc.poll() is None:
+        try:
+            proc.terminate()
+            proc.wait(timeout=grace)
+        except Exception:
+            pass
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)          # the group outlives its leader while any rank is alive; gone already: ESRCH
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        proc.wait(timeout=grace)
+    except Exception:
+        pass
+
+
 def spawn_ranks(n_ranks, program_args, module=None, script=None, env=None, timeout=None, json_only=False):
     """Runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node n_ranks ... <script | -m module> program_args` as a child
-    process.  The ranks' stdout is relayed line by line (rank 0 prints the result line; with json_only every other line goes to
-    stderr so that stdout carries the result line alone), stderr passes through.  Returns the launcher's exit code: non-zero when
-    any rank failed."""
+    process in its own session.  The ranks' stdout is relayed line by line (rank 0 prints the result line; with json_only every other
+    line goes to stderr so that stdout carries the result line alone), stderr passes through.  Returns the launcher's exit code:
+    non-zero when any rank failed, 124 when `timeout` seconds passed (the deadline holds while a hung rank keeps the pipe open: a
+    watchdog thread stops the job, which ends the read loop).  On any exception (KeyboardInterrupt included) the job is stopped first."""
     assert (module is None) != (script is None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_ranks)),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
@@ -40,14 +63,26 @@ def spawn_ranks(n_ranks, program_args, module=None, script=None, env=None, timeo
     child_env = dict(os.environ if env is None else env)
     child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
     child_env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.Popen(cmd, env=child_env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    proc = subprocess.Popen(cmd, env=child_env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+    expired = threading.Event()
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout):
+            expired.set()
+            _stop(proc)
+
+    if timeout is not None:
+        threading.Thread(target=watchdog, daemon=True).start()
     try:
         for line in proc.stdout:
             out = sys.stdout if (not json_only or line.lstrip().startswith("{")) else sys.stderr     # e.g. gloo's connection banners
             out.write(line)
             out.flush()
-        return proc.wait(timeout=timeout)
+        rc = proc.wait()
+        return 124 if expired.is_set() else rc
     except BaseException:
-        proc.kill()          # the exact child we started (its ranks end with their parent's pipe / the launcher's signal handling)
-        proc.wait()
+        _stop(proc)
         raise
+    finally:
+        done.set()

@@ -115,7 +115,7 @@ def _lcg(seed):
         yield float(int(state >> np.uint64(40))) / float(1 << 24)
 
 
-def instanced_cubes(be, n_copies=2309, res=(4096, 4096), env_n=1024, seed=7, spacing=26.0, lens_radius=0.0, metal_every=3, textured=False):
+def instanced_cubes(be, n_copies=2309, res=(4096, 4096), env_n=1024, seed=7, spacing=26.0, lens_radius=0.0, metal_every=3, textured=False, metal_roughness=0.05):
     """n_copies transformed copies of rounded_cube (4332 triangles each) on a jittered 3-D grid, transforms baked into the
     vertices by TriangleMesh::new (triangle.rs:42-58).  2309 copies = 10,002,588 triangles (config 5)."""
     P, N, F = rounded_cube_mesh()
@@ -124,7 +124,7 @@ def instanced_cubes(be, n_copies=2309, res=(4096, 4096), env_n=1024, seed=7, spa
     side = int(np.ceil(n_copies ** (1.0 / 3.0)))
     rnd = _lcg(seed)
     mats = [("matte", dict(Kd=(0.55, 0.55, 0.55))), ("matte", dict(Kd=(0.7, 0.35, 0.25))),
-            ("metal", dict(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.05))]
+            ("metal", dict(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=metal_roughness))]
     if textured:           # checkerboard albedo on the first matte (per-triangle default uvs: the mesh has none)
         b.texture("chk", "spectrum", "checkerboard", uscale=4.0, vscale=4.0, tex1=(0.7, 0.7, 0.7), tex2=(0.25, 0.3, 0.45))
         mats[0] = ("matte", dict(Kd="chk"))

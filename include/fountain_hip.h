@@ -288,10 +288,12 @@ typedef struct ftn_stats {
                                    infinite light only hit / miss matters.  Included in rays_closest (the reference's accounting).      */
     uint64_t quad_records;      /* count_traffic = 2: 128-byte four-box records fetched by the production traversal kernels (both) */
     uint64_t quad_records_any;  /*                    ... the any-hit kernel's share                                               */
-    double any_ms;              /* device time of the any-hit traversal launches (wavefront)                                       */
+    double any_ms;              /* device time of the any-hit traversal launches (wavefront); on small wavefronts they run on a second
+                                 * stream beside the closest-hit launch of the same bounce, so trace_ms and any_ms can overlap in time      */
     uint64_t any_launches;
-    double shade_ms;            /* device time of the classify + shade launches (wavefront)                                        */
-    uint64_t shade_launches;    /* bounces shaded                                                                                  */
+    double shade_ms;            /* device time of the classify and the shade launches (wavefront): two spans per bounce, the second one
+                                 * starts behind the wait for the any-hit results                                                          */
+    uint64_t shade_launches;    /* spans summed into shade_ms (two per bounce)                                                      */
     double sort_ms;             /* device time of the ray-queue coherence sorts (wavefront)                                        */
 } ftn_stats;
 
@@ -357,6 +359,23 @@ int ftn_bvh_quads(const ftn_bvh_node* nodes, uint32_t n_nodes, float* records_ou
 int ftn_scene_info(const ftn_scene* scene, uint32_t* n_nodes, uint32_t* n_prims, uint32_t* n_lights,
                    uint32_t* max_depth, float world_bound[6]);
 int ftn_scene_get_nodes(const ftn_scene* scene, ftn_bvh_node* nodes_out, uint32_t* prim_order_out);
+/* Device bytes the scene holds, per array.  Arrays only a legacy knob reads are not allocated unless that knob is
+ * set when the scene is created: the two-box records (FTN_TRACE4=0 / FTN_QUAD=0) and the indexed attribute arrays (FTN_SREC=0; meshes
+ * with shading tangents keep them). */
+typedef struct ftn_scene_memory {
+    uint64_t nodes;             /* LinearBVHNode records, 32 B each (reference-order kernels: counting builds, exception rays, megakernel) */
+    uint64_t quad;              /* four-box records, 128 B each (production traversal) */
+    uint64_t fat;               /* two-box records, 64 B each (legacy any-hit kernel; 0 unless asked for) */
+    uint64_t geom;              /* triangle vertices, 48 B per primitive (leaf tests) */
+    uint64_t srec;              /* shading records, 128 B per primitive */
+    uint64_t indexed_attributes;/* prim_info + per-vertex normals / uvs / tangents (0 when the shading records carry everything) */
+    uint64_t prim_class;        /* one byte per primitive */
+    uint64_t lights;            /* light records, environment texels and distributions */
+    uint64_t textures;          /* image pyramids */
+    uint64_t other;             /* spheres, materials, statistics block */
+    uint64_t total;
+} ftn_scene_memory;
+int ftn_scene_memory_info(const ftn_scene* scene, ftn_scene_memory* out);
 /* Scene::lights after Scene::new: kind[i] (0 point, 1 distant, 2 infinite, 3 area), prim[i] = BVH-ordered primitive
  * index of an area light's shape or -1 */
 int ftn_scene_get_lights(const ftn_scene* scene, int32_t* kind, int32_t* prim);
@@ -440,6 +459,12 @@ int ftn_test_texture_eval(const ftn_scene* scene, int32_t texture, const float* 
 const char* ftn_last_error(void);
 int ftn_device_count(void);
 const char* ftn_version(void);
+/* Layout version of the structs in this header (ftn_stats, ftn_mesh, ftn_scene_desc, ... are written to / read from caller memory):
+ * a caller built against another header must not call anything else.  The shim compares it with the FTN_ABI_VERSION it was compiled
+ * against when it loads the library.  History: 1 = round 1; 2 = round 2 (ftn_stats 96 -> 152 bytes, ftn_mesh 16 -> 20,
+ * ftn_scene_desc gained `S`); 3 = round 3 (ftn_scene_memory added, no struct changed size). */
+#define FTN_ABI_VERSION 3
+int ftn_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -35,12 +35,15 @@ def test_version_and_error_strings(ftn):
     v = ftn.lib.ftn_version
     v.restype = C.c_char_p
     assert b"gfx950" in v()
+    assert ftn.lib.ftn_abi_version() == A.FTN_ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "fountain_hip.h")).read()
+    assert int(re.search(r"#define\s+FTN_ABI_VERSION\s+(\d+)", header).group(1)) == A.FTN_ABI_VERSION
 
 
 def test_oracle_exports_twins(orc):
     for name in header_functions():
         twin = "orc_" + name[4:]
-        if name in ("ftn_render_device", "ftn_device_count", "ftn_version", "ftn_bvh_build", "ftn_bvh_quads", "ftn_test_math"):
+        if name in ("ftn_render_device", "ftn_device_count", "ftn_version", "ftn_abi_version", "ftn_scene_memory_info", "ftn_bvh_build", "ftn_bvh_quads", "ftn_test_math"):
             continue   # device-only / covered by orc_scene_get_nodes
         if name.startswith(("ftn_pbrt_", "ftn_ply_", "ftn_exr_", "ftn_imageio_")) or name in ("ftn_film_resolve_device", "ftn_test_mipmap_level", "ftn_test_texture_eval"):
             continue   # host-side file ingestion: checked against SceneBuilder in tests/test_pbrt_loader.py

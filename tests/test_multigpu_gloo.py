@@ -26,6 +26,19 @@ def test_sharded_render_equals_whole(tmp_path, world):
     # addends as the single-process merge (a + b is commutative), so the films are identical
     assert np.array_equal(merged.view(np.uint32), whole.view(np.uint32))
     assert merged[..., 3].min() >= 4.0
+    # bench.py's per-rank fields (fountain_amd.distributed.rank_spread): min / max over the ranks of what each rank measured
+    import json
+    spread = json.load(open(out + ".spread.json"))
+    assert spread["device_ms_per_step"] == {"min": 10.0, "max": 10.0 + world - 1} and spread["merge_ms"] == {"min": 1.0, "max": 1.0 + 0.5 * (world - 1)}
+
+
+def test_step_samples_weak_and_strong():
+    from fountain_amd.distributed import rank_spread, step_samples
+    assert [step_samples("weak", n, 16) for n in (1, 2, 4, 8)] == [16, 32, 64, 128]          # every GPU renders 16 spp of its tiles
+    assert [step_samples("strong", n, 16) for n in (1, 2, 4, 8)] == [16, 16, 16, 16]         # the job renders 16 spp, 1/N of the tiles each
+    with pytest.raises(ValueError):
+        step_samples("medium", 2, 16)
+    assert rank_spread({"a": 3.0}) == {"a": {"min": 3.0, "max": 3.0}}                         # no process group: this rank alone
 
 
 def test_tile_shard_partition():
@@ -111,6 +124,29 @@ def test_bench_rank_failure_is_an_error():
     assert r.returncode != 0
 
 
+def test_spawn_ranks_deadline_stops_hung_ranks(tmp_path):
+    """a rank that hangs with its stdout open: the deadline ends the job (exit code 124) and no rank process is left behind"""
+    hang = tmp_path / "hang.py"
+    hang.write_text("import os, sys, time\nopen(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\nprint('started', flush=True)\ntime.sleep(600)\n" % str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from fountain_amd.launch import spawn_ranks; "
+                        "sys.exit(spawn_ranks(2, [], script=%r, timeout=20))" % (ROOT, str(hang))], env=env, capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    import time
+    time.sleep(1.0)
+    pids = [int(open(str(tmp_path / ("pid%d" % k))).read()) for k in range(2)]
+    for pid in pids:
+        alive = os.path.exists("/proc/%d" % pid) and "hang.py" in open("/proc/%d/cmdline" % pid).read().replace("\0", " ")
+        assert not alive, "rank process %d survived the deadline" % pid
+
+
+def test_bench_share_gpu_needs_gloo():
+    """--share-gpu puts every rank on GPU 0, where RCCL would fail with a duplicate-device error: asking for nccl with it is refused"""
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "nccl", "--launch-check"],
+             env=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode == 2 and "gloo" in r.stderr
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_this_box(tmp_path):
     """the whole of `bench.py --gpus 2`, started plainly: two ranks (sharing this box's one GPU, films merged over gloo) render their
@@ -122,4 +158,13 @@ def test_bench_two_ranks_on_this_box(tmp_path):
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 2 and out["config"]["camera_samples_per_step"] == 256 * 256 * 4 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["config"]["camera_samples_per_step"] == 256 * 256 * 4 and out["value"] > 0 and out["scaling"] == "weak"
+    for k in ("device_ms_per_step", "render_wall_ms", "merge_ms"):
+        assert 0 <= out["ranks"][k]["min"] <= out["ranks"][k]["max"], out["ranks"]
+    # the same job with the work fixed (strong scaling): 2 spp of the whole film, each rank half of the tiles
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--copies", "8", "--res", "256", "--spp-per-gpu", "2", "--steps", "2", "--scaling", "strong",
+                        "--warmup", "1", "--share-gpu", "--no-cpu-baseline"], env=dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["camera_samples_per_step"] == 256 * 256 * 2

@@ -1,7 +1,7 @@
 """Builds profiles/<round>/traffic.json -- the PMC side of bench.py's roofline block -- from rocprofv3 counter passes over bench.py itself.
 
 Run ON THE GPU BOX (from the repository root):
-    python tools/make_traffic_json.py profiles/r02 [--spp-per-gpu 16]
+    python tools/make_traffic_json.py profiles/r03 [--spp-per-gpu 16]
 It runs `bench.py --steps 1 --warmup 0 --no-cpu-baseline` once per counter group under
 `rocprofv3 --pmc <counters> --kernel-trace --output-format csv` (separate passes: the TCC block has four slots and FETCH_SIZE /
 WRITE_SIZE do not fit together, MI355X_MICROARCH.md "rocprofv3 PMC slots"), sums every counter per kernel group and per timed step,
@@ -26,6 +26,7 @@ SOURCES = ["fountain_amd/csrc/ftn_trace4.hip", "fountain_amd/csrc/ftn_wavefront.
 PASSES = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum"]),
           ("tcc2", ["TCC_REQ_sum", "TCC_READ_sum", "TCC_WRITE_sum", "TCC_ATOMIC_sum"]), ("tcc3", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]),
           ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY"]),
+          ("sq2", ["SQ_THREAD_CYCLES_VALU", "SQ_INSTS_LDS"]),
           ("grbm", ["GRBM_GUI_ACTIVE"])]
 
 
@@ -39,7 +40,7 @@ def source_hash():
 def group_of(name):
     """kernel name -> (group, counting build?)"""
     n = name
-    counting = ("k_wf_trace4<true" in n) or ("k_wf_trace4_any<true" in n) or ("k_wf_trace<false, true" in n) or ("k_wf_trace<true, true" in n)
+    counting = ("k_wf_trace4<true" in n) or ("k_wf_trace4_any<true" in n) or ("k_wf_trace4_any_dual<true" in n) or ("k_wf_trace<false, true" in n) or ("k_wf_trace<true, true" in n)
     if "k_wf_trace4_any" in n or "k_wf_trace_any2" in n or "k_wf_trace<true" in n:
         return "any_hit", counting
     if "k_wf_trace4" in n or "k_wf_trace<false" in n:
@@ -54,7 +55,7 @@ def group_of(name):
 
 
 def main():
-    out_dir = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02"
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03"
     extra = sys.argv[2:]
     out_dir = os.path.join(ROOT, out_dir) if not os.path.isabs(out_dir) else out_dir
     os.makedirs(out_dir, exist_ok=True)
@@ -109,6 +110,7 @@ def main():
                      # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
                      "valu_busy": (c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)) if c.get("GRBM_GUI_ACTIVE") else None,
                      "wave_cycles_waiting_on_memory": (c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+                     "lanes_per_valu_inst": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None,
                      "gpu_cycles": c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0, "launches_per_step": launches.get(g, 0)}
     cfg = (bench_line or {}).get("config", {})
     out = {"source_hash": source_hash(), "sources": SOURCES, "workload": cfg.get("workload"), "per_gpu_workload": cfg.get("per_gpu_workload"), "bench_args": extra,
@@ -116,7 +118,8 @@ def main():
                                "hbm_bytes_per_launch": hbm_bytes(dominant) / max(launches.get("closest_dominant", 0), 1),
                                "l2_hit_rate": dominant.get("TCC_HIT_sum", 0.0) / max(dominant.get("TCC_HIT_sum", 0.0) + dominant.get("TCC_MISS_sum", 0.0), 1.0),
                                "valu_busy": (dominant.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * dominant["GRBM_GUI_ACTIVE"] / 8.0)) if dominant.get("GRBM_GUI_ACTIVE") else None,
-                               "wave_cycles_waiting_on_memory": (dominant.get("SQ_WAIT_ANY", 0.0) / dominant["SQ_WAVE_CYCLES"]) if dominant.get("SQ_WAVE_CYCLES") else None},
+                               "wave_cycles_waiting_on_memory": (dominant.get("SQ_WAIT_ANY", 0.0) / dominant["SQ_WAVE_CYCLES"]) if dominant.get("SQ_WAVE_CYCLES") else None,
+                               "lanes_per_valu_inst": (dominant["SQ_THREAD_CYCLES_VALU"] / dominant["SQ_ACTIVE_INST_VALU"]) if dominant.get("SQ_THREAD_CYCLES_VALU") and dominant.get("SQ_ACTIVE_INST_VALU") else None},
            "groups": groups,
            "kernels": {k: {"launches_per_step": int(c.get("launches", 0)), "hbm_bytes_per_step": hbm_bytes(c), "read_bytes_per_step": c.get("FETCH_SIZE", 0.0) * 2048.0,
                            "write_bytes_per_step": c.get("WRITE_SIZE", 0.0) * 1024.0,
