@@ -167,5 +167,5 @@ DECLARED_FUNCTIONS = [
     "ftn_last_error", "ftn_device_count", "ftn_version", "ftn_abi_version", "ftn_scene_memory_info", "ftn_test_math",
     "ftn_pbrt_load", "ftn_pbrt_destroy", "ftn_pbrt_scene", "ftn_pbrt_camera", "ftn_pbrt_film",
     "ftn_pbrt_samples_per_pixel", "ftn_pbrt_film_name", "ftn_pbrt_last_error", "ftn_ply_load",
-    "ftn_test_mipmap_level", "ftn_test_texture_eval", "ftn_film_resolve_device", "ftn_exr_write", "ftn_exr_read", "ftn_imageio_last_error",
+    "ftn_test_mipmap_level", "ftn_test_texture_eval", "ftn_film_resolve_device", "ftn_exr_write", "ftn_exr_read", "ftn_imageio_last_error", "ftn_image_inverse_gamma",
 ]

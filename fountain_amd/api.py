@@ -361,13 +361,14 @@ class SceneBuilder:
         elif cls == "uv":
             idx = self._new_texture(A.FTN_TEX_UV, False, mapping=mapping)
         else:   # make_imagemap_spect (constructors.rs:295-318) -> load_mipmap (imageio/mod.rs:81-124): scale, flip_y = true
-            if kw.get("gamma", False):
-                raise FountainError(A.FTN_ERR_UNSUPPORTED, "gamma-encoded image maps are not supported (EXR input is linear)")
             tex = kw.get("texels")
             if tex is None:
                 tex = read_exr(kw["filename"], self.be)
             wrap = {"repeat": A.FTN_WRAP_REPEAT, "black": A.FTN_WRAP_BLACK, "clamp": A.FTN_WRAP_CLAMP}[kw.get("wrap", "repeat")]
-            tex = np.asarray(tex, np.float32) * np.float32(kw.get("scale", 1.0))
+            tex = np.array(tex, np.float32, order="C")                 # (a copy: the gamma step works in place)
+            if kw.get("gamma", False):                                  # imageio/mod.rs:86-107: given -> as given; default false for .exr input
+                self.be.call("image_inverse_gamma", tex.ctypes.data_as(C.c_void_p), C.c_size_t(tex.size))
+            tex = tex * np.float32(kw.get("scale", 1.0))
             tex = np.ascontiguousarray(tex[::-1])
             self.images.append((tex, wrap))
             idx = self._new_texture(A.FTN_TEX_IMAGE, False, image=len(self.images) - 1, mapping=mapping)

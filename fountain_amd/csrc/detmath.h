@@ -244,5 +244,46 @@ FTN_HD float log2f_det(float xf) {
     return (float)((double)e + lm * 1.44269504088896340736);
 }
 
+/* ---- exp on binary64: t = k ln2 + r, |r| <= ln2 / 2, Taylor to r^13 (remainder below 1e-17), scaled by 2^k */
+FTN_HD double kexp(double t) {
+    if (!(t == t)) return t;
+    if (t > 709.0) return u2d(0x7ff0000000000000ULL);
+    if (t < -745.0) return 0.0;
+    const double kf = floor(t * 1.44269504088896340736 + 0.5);
+    const double r = (t - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;               /* 1/13! */
+    p = 1.0 / 479001600.0 + r * p;
+    p = 1.0 / 39916800.0 + r * p;
+    p = 1.0 / 3628800.0 + r * p;
+    p = 1.0 / 362880.0 + r * p;
+    p = 1.0 / 40320.0 + r * p;
+    p = 1.0 / 5040.0 + r * p;
+    p = 1.0 / 720.0 + r * p;
+    p = 1.0 / 120.0 + r * p;
+    p = 1.0 / 24.0 + r * p;
+    p = 1.0 / 6.0 + r * p;
+    p = 0.5 + r * p;
+    p = 1.0 + r * p;
+    p = 1.0 + r * p;
+    /* 2^k in two factors so that results in the binary64 subnormal range (binary32 zero anyway) stay finite operations */
+    const int k = (int)kf, k1 = k / 2, k2 = k - k1;
+    return (p * u2d((uint64_t)(k1 + 1023) << 52)) * u2d((uint64_t)(k2 + 1023) << 52);
+}
+
+/* f32::powf for a positive base (the only use: imageio/mod.rs:173, ((v + 0.055) / 1.055).powf(2.4) with v > 0.04045): exp(y ln x)
+ * in binary64, rounded once.  x <= 0, NaN and infinities follow IEEE pow for a non-integer y. */
+FTN_HD_NOINLINE float powf_det(float xf, float yf) {
+    if (!(xf == xf) || !(yf == yf)) return xf + yf;
+    if (yf == 0.0f || xf == 1.0f) return 1.0f;
+    if (xf < 0.0f) return u2f(0x7fc00000u);
+    if (xf == 0.0f) return yf > 0.0f ? 0.0f : u2f(0x7f800000u);
+    if (xf - xf != 0.0f) return yf > 0.0f ? xf : 0.0f;        /* +inf */
+    int e;
+    const double lm = klog_parts((double)xf, &e);
+    const double ef = (double)e;
+    const double lx = (ef * 6.93147180369123816490e-01 + lm) + ef * 1.90821492927058770002e-10;
+    return (float)kexp((double)yf * lx);
+}
+
 }  // namespace ftn_det
 #endif

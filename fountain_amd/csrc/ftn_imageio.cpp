@@ -7,6 +7,7 @@
  * reference's writer produce, plus the usual encoding of environment maps and textures found in PBRT scenes; zlib inflates).
  */
 #include "../../include/fountain_hip.h"
+#include "detmath.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -185,3 +186,14 @@ int ftn_exr_read(const char* path, uint32_t* w_out, uint32_t* h_out, float* rgb_
 }
 
 }  // extern "C"
+
+/* load_mipmap's gamma step: imageio/mod.rs:101-107 with inverse_gamma_correct (:169-175); f32::powf through the deterministic powf
+ * (detmath.h), like every other transcendental of this library */
+int ftn_image_inverse_gamma(float* texels, size_t n) {
+    if (!texels && n) return io_fail(FTN_ERR_INVALID_ARGUMENT, "null texel array");
+    for (size_t i = 0; i < n; i++) {
+        const float v = texels[i];
+        texels[i] = v <= 0.04045f ? v * 1.0f / 12.92f : ftn_det::powf_det((v + 0.055f) * 1.0f / 1.055f, 2.4f);
+    }
+    return FTN_OK;
+}

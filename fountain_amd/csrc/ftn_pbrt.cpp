@@ -259,7 +259,6 @@ int add_texture(ftn_pbrt* S, const std::string& name, std::string ty, const std:
         if (fn == ps.end() || fn->second.s.empty()) return fail(S, FTN_ERR_INVALID_ARGUMENT, "ParamError: filename");
         const std::string file = S->base_dir + "/" + fn->second.s[0];
         if (file.size() < 4 || file.substr(file.size() - 4) != ".exr") return fail(S, FTN_ERR_UNSUPPORTED, "image maps are read from OpenEXR files only");
-        if (getb(ps, "gamma", false)) return fail(S, FTN_ERR_UNSUPPORTED, "gamma-encoded image maps are not supported (EXR input is linear)");
         uint32_t wrap = FTN_WRAP_REPEAT;
         { auto it = ps.find("wrap"); if (it != ps.end() && !it->second.s.empty()) { const std::string& w = it->second.s[0];
             if (w == "repeat") wrap = FTN_WRAP_REPEAT; else if (w == "black") wrap = FTN_WRAP_BLACK; else if (w == "clamp") wrap = FTN_WRAP_CLAMP; else return fail(S, FTN_ERR_INVALID_ARGUMENT, "Unknown repeat type " + w); } }
@@ -267,7 +266,10 @@ int add_texture(ftn_pbrt* S, const std::string& name, std::string ty, const std:
         if ((rc = ftn_exr_read(file.c_str(), &im.w, &im.h, nullptr))) return fail(S, rc, ftn_imageio_last_error());
         im.texels.resize((size_t)im.w * im.h * 3);
         if ((rc = ftn_exr_read(file.c_str(), &im.w, &im.h, im.texels.data()))) return fail(S, rc, ftn_imageio_last_error());
-        const float scale = getf(ps, "scale", 1.0f);                         /* load_mipmap: texel * scale, then the y flip (imageio/mod.rs:100-117) */
+        /* load_mipmap (imageio/mod.rs:86-117): `gamma` given -> as given, otherwise false for .exr (the only extension read here); the
+         * gamma step first, then texel * scale, then the y flip */
+        if (getb(ps, "gamma", false)) (void)ftn_image_inverse_gamma(im.texels.data(), im.texels.size());
+        const float scale = getf(ps, "scale", 1.0f);
         for (float& t : im.texels) t = t * scale;
         for (uint32_t y = 0; y < im.h / 2; y++) for (uint32_t x = 0; x < im.w * 3; x++) std::swap(im.texels[(size_t)y * im.w * 3 + x], im.texels[(size_t)(im.h - 1 - y) * im.w * 3 + x]);
         S->image_store.push_back(std::move(im));

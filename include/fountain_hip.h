@@ -435,6 +435,10 @@ int ftn_ply_load(const char* path, uint32_t* n_vertices, uint32_t* n_triangles, 
 /* ------------------------------------------------------------------ output stage
  * Film::into_spectrum_buffer (src/film.rs:195-210) on the device: device_pixels -> device_rgb (3 floats per pixel), both DEVICE
  * pointers, on `stream`.  Bit-identical to ftn_film_resolve on the host.                                                  */
+/* load_mipmap's gamma step (imageio/mod.rs:101-107, 169-175): every channel value v of a gamma-encoded image map becomes
+ * v / 12.92 (v <= 0.04045) or ((v + 0.055) / 1.055)^2.4 -- BEFORE the texture's `scale` is applied.  In place, n floats, host memory.
+ * The reference applies it to every non-EXR map and to any map with `"bool gamma" "true"`. */
+int ftn_image_inverse_gamma(float* texels, size_t n);
 int ftn_film_resolve_device(const void* device_pixels, size_t n_pixels, void* device_rgb_out, void* stream);
 /* write_exr / read_exr (src/imageio/exr.rs:11-87): scanline OpenEXR, FLOAT channels R G B, layer "image"; rgb is row-major,
  * 3 floats per pixel.  The writer emits NO_COMPRESSION blocks (the reference's `exr` crate writes RLE: same samples, same layer);

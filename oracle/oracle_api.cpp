@@ -278,9 +278,12 @@ int orc_kat_sphere_intersect(const ftn_sphere* sp, const float ray8[8], float ou
 }
 float orc_kat_math(int which, float x, float y) {
     switch (which) { case 0: return m_sin(x); case 1: return m_cos(x); case 2: return m_tan(x); case 3: return m_acos(x);
-                     case 4: return m_atan(x); case 5: return m_atan2(x, y); case 6: return m_ln(x); case 7: return m_log2(x); default: return 0.0f; }
+                     case 4: return m_atan(x); case 5: return m_atan2(x, y); case 6: return m_ln(x); case 7: return m_log2(x); case 13: return m_pow(x, y); default: return 0.0f; }
 }
 float orc_kat_roughness_to_alpha(float r) { return roughness_to_alpha(r); }
+// imageio/mod.rs:169-175 inverse_gamma_correct, applied by load_mipmap (imageio/mod.rs:101-107) to every channel of a gamma-encoded map
+static inline Float inverse_gamma_correct(Float v) { return v <= 0.04045f ? v * 1.0f / 12.92f : m_pow((v + 0.055f) * 1.0f / 1.055f, 2.4f); }
+int orc_image_inverse_gamma(float* texels, size_t n) { if (!texels && n) return FTN_ERR_INVALID_ARGUMENT; for (size_t i = 0; i < n; i++) texels[i] = inverse_gamma_correct(texels[i]); return FTN_OK; }
 // Bounds2i::iter_points / iter_tiles (bounds.rs:76-97): out holds 2 ints per point / 4 per tile; returns the count
 size_t orc_kat_iter_points(const int32_t b[4], int32_t* out, size_t cap) {
     size_t n = 0;

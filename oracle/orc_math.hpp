@@ -41,6 +41,7 @@ inline Float m_atan(Float x) { return ftn_det::atanf_det(x); }
 inline Float m_atan2(Float y, Float x) { return ftn_det::atan2f_det(y, x); }
 inline Float m_ln(Float x) { return ftn_det::logf_det(x); }
 inline Float m_log2(Float x) { return ftn_det::log2f_det(x); }
+inline Float m_pow(Float x, Float y) { return ftn_det::powf_det(x, y); }
 #else
 inline Float m_sin(Float x) { return sinf(x); }
 inline Float m_cos(Float x) { return cosf(x); }
@@ -50,6 +51,7 @@ inline Float m_atan(Float x) { return atanf(x); }
 inline Float m_atan2(Float y, Float x) { return atan2f(y, x); }
 inline Float m_ln(Float x) { return logf(x); }
 inline Float m_log2(Float x) { return log2f(x); }
+inline Float m_pow(Float x, Float y) { return powf(x, y); }
 #endif
 
 // ---- Rust float semantics helpers

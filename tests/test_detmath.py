@@ -30,6 +30,18 @@ def test_accuracy_vs_correct_rounding(orc_det, which):
     assert ulp.max() <= 1.0, name
 
 
+def test_powf_correctly_rounded(orc_det):
+    """f32::powf for a positive base (imageio/mod.rs:173 is its only caller on this path): exp(y ln x) in binary64, one rounding"""
+    rng = np.random.default_rng(13)
+    x = np.concatenate([rng.uniform(0.09, 1.0, 15000), rng.uniform(1e-3, 60.0, 5000)]).astype(f32)
+    y = np.concatenate([np.full(15000, 2.4), rng.uniform(-3.0, 3.0, 5000)]).astype(f32)
+    got = host_eval(orc_det, 13, x, y)
+    exact = np.power(x.astype(np.float64), y.astype(np.float64))
+    assert (got != exact.astype(f32)).mean() <= 1e-3
+    assert (np.abs(got.astype(np.float64) - exact) / np.spacing(np.abs(exact.astype(f32))).astype(np.float64)).max() <= 1.0
+    assert list(host_eval(orc_det, 13, f32([1.0, 4.0, 0.0, 2.0]), f32([7.5, 0.5, 2.4, 0.0]))) == [1.0, 2.0, 0.0, 1.0]
+
+
 def test_atan2_and_special_values(orc_det):
     rng = np.random.default_rng(5)
     y, x = rng.uniform(-5, 5, 20000).astype(f32), rng.uniform(-5, 5, 20000).astype(f32)

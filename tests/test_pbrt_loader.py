@@ -263,6 +263,7 @@ Texture "chk" "spectrum" "checkerboard" "float uscale" 8 "float vscale" 4 "rgb t
 Texture "fchk" "float" "checkerboard" "float tex1" 0 "float tex2" 30 "float udelta" 0.5
 Texture "grid" "color" "uv" "float uscale" 2 "float vdelta" 0.25
 Texture "img" "spectrum" "imagemap" "string filename" "t.exr" "string wrap" "clamp" "float scale" 0.5
+Texture "imgg" "spectrum" "imagemap" "string filename" "t.exr" "bool gamma" "true" "float scale" 2
 Texture "nest" "spectrum" "checkerboard" "texture tex1" "grid" "texture tex2" "img"
 Material "matte" "texture Kd" "chk" "texture sigma" "fchk"
 Shape "sphere"
@@ -293,6 +294,7 @@ def test_texture_statements(ftn, tmp_path):
     b.texture("fchk", "float", "checkerboard", tex1=0.0, tex2=30.0, udelta=0.5)
     b.texture("grid", "color", "uv", uscale=2.0, vdelta=0.25)
     b.texture("img", "spectrum", "imagemap", texels=img, wrap="clamp", scale=0.5)
+    b.texture("imgg", "spectrum", "imagemap", texels=img, gamma=True, scale=2.0)         # "bool gamma" "true": inverse_gamma_correct, THEN the scale
     b.texture("nest", "spectrum", "checkerboard", tex1="grid", tex2="img")
     b.material("matte", Kd="chk", sigma="fchk"); b.shape("sphere")
     b.material("matte", Kd="fchk"); b.shape("sphere", radius=2.0)             # float texture in a spectrum slot -> the default 0.5
@@ -302,10 +304,15 @@ def test_texture_statements(ftn, tmp_path):
     b.material("glass", Kr="grid", Kt="chk", uroughness="fchk", vroughness=0.2); b.shape("sphere", radius=6.0)
     d, keep = b.build_desc()
     assert_same_desc(ps.desc, d)
-    assert d.n_textures == 9 and d.n_images == 1 and list(d.materials[2].a) == [0.5, 0.5, 0.5] and d.material_textures[2].a == -1
+    assert d.n_textures == 10 and d.n_images == 2 and list(d.materials[2].a) == [0.5, 0.5, 0.5] and d.material_textures[2].a == -1
     # the stored image is the file flipped in y and scaled (load_mipmap, imageio/mod.rs:100-117)
     got = np.frombuffer(C.string_at(C.cast(ps.desc.images[0].texels, C.c_void_p), 6 * 10 * 3 * 4), np.float32).reshape(6, 10, 3)
     assert np.array_equal(got, (img * np.float32(0.5))[::-1])
+    # the gamma-encoded map (imageio/mod.rs:101-107, 169-175): v / 12.92 below 0.04045, ((v + 0.055) / 1.055)^2.4 above, then * scale, then the flip
+    gg = np.frombuffer(C.string_at(C.cast(ps.desc.images[1].texels, C.c_void_p), 6 * 10 * 3 * 4), np.float32).reshape(6, 10, 3)
+    v = img.astype(np.float64)
+    want = np.where(img <= np.float32(0.04045), v / 12.92, ((v + 0.055) / 1.055) ** 2.4) * 2.0
+    assert np.allclose(gg, want[::-1], rtol=3e-7, atol=0) and not np.array_equal(gg, (img * np.float32(2.0))[::-1])
 
 
 # ------------------------------------------------------------------ SURVEY 8(f).1 on the GPU: parsed scene files rendered by the HIP path vs the oracle

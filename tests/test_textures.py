@@ -166,6 +166,33 @@ def test_uv_textured_quad_shows_its_uvs(orc, integ):
     assert np.allclose(np.sort(uu), u, atol=0.02) and np.allclose(np.sort(rgb[:, 16, 1]), u, atol=0.02)
 
 
+def test_gamma_encoded_image_maps(ftn, orc, orc_det):
+    """load_mipmap's gamma step (imageio/mod.rs:86-107, inverse_gamma_correct :169-175): linear below 0.04045, the 2.4 power above, the
+    texture's scale AFTER it.  The product's host function equals the oracle's deterministic build bit for bit and the libm build
+    (f32::powf as rustc links it) to within one ulp; SceneBuilder.texture(gamma=True) stores the decoded texels."""
+    rng = np.random.default_rng(8)
+    v = np.concatenate([rng.random(20000), rng.random(2000) * 0.05, [0.0, 0.04045, 0.040450003, 1.0, 2.5]]).astype(np.float32)
+    outs = []
+    for be in (ftn, orc_det, orc):
+        a = v.copy()
+        be.call("image_inverse_gamma", a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size))
+        outs.append(a)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    ulp = np.abs(outs[0].astype(np.float64) - outs[2].astype(np.float64)) / np.spacing(np.maximum(np.abs(outs[2]), np.float32(1e-30))).astype(np.float64)
+    assert ulp.max() <= 1.0
+    lin = v <= np.float32(0.04045)
+    assert np.array_equal(outs[0][lin], (v[lin] * np.float32(1.0)) / np.float32(12.92))
+    want = ((v[~lin].astype(np.float64) + np.float64(np.float32(0.055))) / np.float64(np.float32(1.055))) ** np.float64(np.float32(2.4))
+    assert np.allclose(outs[0][~lin], want, rtol=3e-7, atol=0) and outs[0][-2] == np.float32(1.0)
+    img = rng.random((5, 7, 3)).astype(np.float32)
+    for be in (ftn, orc_det):
+        b = SceneBuilder(be)
+        b.texture("g", "spectrum", "imagemap", texels=img, gamma=True, scale=0.5)
+        dec = img.copy()
+        be.call("image_inverse_gamma", dec.ctypes.data_as(C.c_void_p), C.c_size_t(dec.size))
+        assert np.array_equal(b.images[0][0], (dec * np.float32(0.5))[::-1])
+
+
 # ------------------------------------------------------------------ GPU parity
 def textured_scene(be, img):
     """checkerboard floor (mesh with uvs), image-mapped sphere, uv-mapped mesh without uvs (default uvs), nested texture on a
@@ -174,7 +201,7 @@ def textured_scene(be, img):
     b = SceneBuilder(be)
     b.texture("chk", "spectrum", "checkerboard", uscale=6.0, vscale=6.0, tex1=(0.15, 0.15, 0.2), tex2=(0.8, 0.75, 0.7))
     b.texture("img", "spectrum", "imagemap", texels=img, wrap="repeat", uscale=2.0, vscale=2.0)
-    b.texture("imgc", "spectrum", "imagemap", texels=img, wrap="clamp", scale=0.8)
+    b.texture("imgc", "spectrum", "imagemap", texels=img, wrap="clamp", scale=0.8, gamma=True)       # a gamma-encoded map (imageio/mod.rs:101-107)
     b.texture("grid", "spectrum", "uv", uscale=4.0, vscale=4.0)
     b.texture("rough", "float", "checkerboard", uscale=5.0, vscale=3.0, tex1=0.05, tex2=0.4)
     b.texture("nest", "spectrum", "checkerboard", uscale=2.0, vscale=2.0, tex1="grid", tex2="imgc")
