@@ -1052,7 +1052,7 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
     /* the wavefront pipeline renders the indexed sampler; PathIntegrator always, DirectLightingIntegrator / WhittedIntegrator for scenes
      * without textures (their texture differentials follow the specular chain: megakernel) and, Whitted, with at most 4 lights */
-    const bool wf_ok = indexed && (id->kind == FTN_INTEGRATOR_PATH || (s->d.n_textures == 0 && (id->kind == FTN_INTEGRATOR_DIRECT_LIGHTING || s->d.n_lights <= 4u)));
+    const bool wf_ok = indexed && (id->kind != FTN_INTEGRATOR_WHITTED || s->d.n_lights <= 32u);      /* (Whitted: one bit per light in a path's pending-light word) */
     if (pipeline == FTN_PIPELINE_AUTO) pipeline = wf_ok ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
     if (pipeline == FTN_PIPELINE_WAVEFRONT && !wf_ok)
         return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED; DirectLightingIntegrator / WhittedIntegrator only without textures (Whitted: up to 4 lights)");

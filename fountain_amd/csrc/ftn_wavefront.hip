@@ -636,10 +636,13 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
  * the same deferred shadow / MIS rays as the path integrator (resolved when the path comes back after the traces), but called for every
  * BSDF (no "has non-specular lobes" test) and not weighted by a throughput.  WhittedIntegrator: every light once, one 2D sample and one
  * shadow ray each (ray l of path p in slot p + l * n_paths), up to WF_WH_MAX_LIGHTS lights; no MIS ray, no emitted term.
+ * TEX (scenes with textures): texture lookups need the ray differentials, which these integrators carry along the specular chain
+ * (specular_reflect updates them, integrator/mod.rs:58-84): level 0 rebuilds the camera ray's from the path's sample key (as k_wf_shade
+ * does at every bounce), deeper levels read what the level above stored in WfBuffers::dfd.
  * The 2D sample of specular_transmit is drawn after the reflect recursion returns and never used by a supported material: with one
  * stream per camera sample (the indexed sampler, the only one the wavefront runs) skipping it changes nothing. */
 #define WF_DL_MAX 8u
-#define WF_WH_MAX_LIGHTS 4u
+#define WF_WH_MAX_LIGHTS 32u     /* one bit per light in the path's pending-light word */
 __device__ inline void dl_unwind(const RenderParams& P, const WfBuffers& W, uint32_t p, uint32_t depth, bool have_tail, Rgb tail) {
     Rgb li = have_tail ? tail : Rgb(0.0f);
     bool child = have_tail;
@@ -654,7 +657,7 @@ __device__ inline void dl_unwind(const RenderParams& P, const WfBuffers& W, uint
     W.rad[p] = make_float4(li.r, li.g, li.b, 0.0f);
 }
 
-template <bool WHITTED>
+template <bool WHITTED, bool TEX>
 __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W, int in_q) {
     const DScene& S = P.S;
     uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
@@ -741,7 +744,27 @@ __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W
                 else {
                     DSI si; make_interaction(S, h, ray0, &si);
                     DBsdf B;
-                    if (si.mat < 0 || !make_bsdf<-1>(S.materials[si.mat], si, false, &B)) { err = FTN_ERR_UNSUPPORTED; ended = true; }
+                    ftn_material mloc; const ftn_material* mp = si.mat >= 0 ? &S.materials[si.mat] : nullptr;
+                    DSIX ex; DTexDiffs td; float bsdf_eta = 1.0f; DRayDiff rd; rd.has = false;
+                    if (TEX && mp) {                              /* as direct_li<TEX> (ftn_kernels.hip): differentials of this level, textured parameters resolved per hit */
+                        if (depth == 0u) {
+                            const uint32_t slot = p / W.samples, sidx = p % W.samples;
+                            const DTile tile = P.tiles[slot >> 8];
+                            const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
+                            Rng crng; crng.seed(indexed_key(P.seed, px, py, W.first_sample + sidx));
+                            const V2 j = crng.next2(); const V2 p_film((float)px + j.x, (float)py + j.y); const V2 p_lens = crng.next2(); const float time_u = crng.next();
+                            const DRay cam = camera_ray(P.C, p_film, p_lens, time_u);
+                            rd = camera_ray_diff(P.C, p_film, p_lens, cam, 1.0f / sqrtf((float)P.spp));
+                        } else {
+                            const float4 d0 = W.dfd[p], d1 = W.dfd[(size_t)W.n_paths + p], d2 = W.dfd[2 * (size_t)W.n_paths + p];
+                            rd.has = true; rd.rxo = V3(d0.x, d0.y, d0.z); rd.ryo = V3(d1.x, d1.y, d1.z); rd.ryd = V3(d2.x, d2.y, d2.z); rd.rxd = V3(d0.w, d1.w, d2.w);
+                        }
+                        DSI s2; make_interaction(S, h, ray0, &s2, &ex);
+                        td = compute_tex_diffs(si.hit.p, si.hit.n, ex.dpdu, ex.dpdv, rd);
+                        if (material_is_textured(S, si.mat)) { mloc = material_resolve(S, si.mat, ex.uv, td); mp = &mloc; }
+                        if (mp->type == FTN_MAT_GLASS) bsdf_eta = mp->s0;
+                    }
+                    if (!mp || !make_bsdf<-1>(*mp, si, false, &B)) { err = FTN_ERR_UNSUPPORTED; ended = true; }
                     else {
                         Rng rng; { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
                         Rgb rad(0.0f);
@@ -817,6 +840,11 @@ __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W
                             if (has_t) err = FTN_ERR_UNSUPPORTED;              /* specular transmission: glass.rs:66 todo!() */
                             else if (has_r) {
                                 lvA.w = sr.pdf; lvB = make_float4(sr.f.r, sr.f.g, sr.f.b, fabsf(dot(sr.wi, si.shading_n)));
+                                if (TEX) {                            /* the reflected ray's differentials, for the next level's lookups (mod.rs:58-84) */
+                                    rd = specular_diff(true, rd, si.hit.p, si.wo, sr.wi, si.shading_n, ex.dndu, ex.dndv, td, bsdf_eta);
+                                    W.dfd[p] = make_float4(rd.rxo.x, rd.rxo.y, rd.rxo.z, rd.rxd.x); W.dfd[(size_t)W.n_paths + p] = make_float4(rd.ryo.x, rd.ryo.y, rd.ryo.z, rd.rxd.y);
+                                    W.dfd[2 * (size_t)W.n_paths + p] = make_float4(rd.ryd.x, rd.ryd.y, rd.ryd.z, rd.rxd.z);
+                                }
                                 DRay nr = spawn_ray(si.hit, sr.wi);
                                 W.ray[2 * (size_t)(p)] = make_float4(nr.o.x, nr.o.y, nr.o.z, 0.0f); W.ray[2 * (size_t)(p) + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, nr.t_max);
                                 alive = true; push_closest = true;
@@ -845,7 +873,7 @@ __global__ void __launch_bounds__(256) k_wf_shade_dl(RenderParams P, WfBuffers W
             block_push<5>(pred, val, qs, cs);
         }
         /* shadow rays: slot p + l * n_paths (direct lighting: l = 0 only) -- queue entries are slots; the any-hit kernels read W.sh[2 * slot] */
-        for (uint32_t l = 0; l < (WHITTED ? WF_WH_MAX_LIGHTS : 1u); l++) {
+        for (uint32_t l = 0; l < (WHITTED ? nl : 1u); l++) {
             const bool on = ((sh_mask >> l) & 1u) != 0;
             const bool pred[1] = {on};
             const uint32_t val[1] = {p + l * W.n_paths};
@@ -992,7 +1020,7 @@ struct WavefrontState {
     int n_cu = 256;
     /* four-box traversal (ftn_trace4.hip): launch plan of the current call and the global spill areas behind the LDS stacks */
     /* buffers of the direct-lighting / Whitted mode (grow-only): level terms, and shadow-ray records / results / queue sized for one ray per light */
-    void* dl_mem[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dl_paths = 0; uint32_t dl_levels = 0, dl_slots = 0;
+    void* dl_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dl_paths = 0; uint32_t dl_levels = 0, dl_slots = 0; bool dl_tex = false;
     Trace4Plan t4; bool t4_on = false, t4_dual = false;
     void* t4_spill_c = nullptr; void* t4_spill_a = nullptr; size_t t4_spill_c_bytes = 0, t4_spill_a_bytes = 0;
 };
@@ -1027,7 +1055,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 4 * n) /* up to WF_WH_MAX_LIGHTS shadow rays per path */) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
+        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -1133,11 +1161,11 @@ static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, 
 #undef FTN_TR
 }
 
-/* buffers of k_wf_shade_dl for n paths, `levels` chain levels and `slots` shadow rays per path */
-static int wf_reserve_dl(WavefrontState* st, size_t n, uint32_t levels, uint32_t slots) {
-    if (n <= st->dl_paths && levels <= st->dl_levels && slots <= st->dl_slots) return FTN_OK;
-    for (void*& m : st->dl_mem) { if (m) (void)hipFree(m); m = nullptr; }
-    st->dl_paths = 0;
+/* buffers of k_wf_shade_dl for n paths, `levels` chain levels and `slots` shadow rays per path; tex: the differentials of textured scenes */
+static void wf_free_dl(WavefrontState* st) { for (void*& m : st->dl_mem) { if (m) (void)hipFree(m); m = nullptr; } st->dl_paths = 0; st->dl_levels = 0; st->dl_slots = 0; st->dl_tex = false; }
+static int wf_reserve_dl(WavefrontState* st, size_t n, uint32_t levels, uint32_t slots, bool tex) {
+    if (n <= st->dl_paths && levels <= st->dl_levels && slots <= st->dl_slots && (!tex || st->dl_tex)) return FTN_OK;
+    wf_free_dl(st);
     const size_t sl = std::max<uint32_t>(slots, 2u);                       /* (direct lighting: shadow results at [0, n), MIS-any results at [n, 2n)) */
     WF_TRY(hipMalloc(&st->dl_mem[0], (size_t)levels * n * sizeof(float4)));          /* dlA */
     WF_TRY(hipMalloc(&st->dl_mem[1], (size_t)levels * n * sizeof(float4)));          /* dlB */
@@ -1145,7 +1173,9 @@ static int wf_reserve_dl(WavefrontState* st, size_t n, uint32_t levels, uint32_t
     WF_TRY(hipMalloc(&st->dl_mem[3], 2 * (size_t)slots * n * sizeof(float4)));       /* shadow-ray records */
     WF_TRY(hipMalloc(&st->dl_mem[4], sl * n));                                       /* occluded */
     WF_TRY(hipMalloc(&st->dl_mem[5], sl * n * sizeof(uint32_t)));                    /* any-hit queue */
-    st->dl_paths = n; st->dl_levels = levels; st->dl_slots = slots;
+    WF_TRY(hipMalloc(&st->dl_mem[6], sl * n * sizeof(uint32_t)));                    /* ... and the queue of the rays the four-box kernel hands back */
+    if (tex) WF_TRY(hipMalloc(&st->dl_mem[7], 3 * n * sizeof(float4)));              /* dfd */
+    st->dl_paths = n; st->dl_levels = levels; st->dl_slots = slots; st->dl_tex = tex;
     return FTN_OK;
 }
 
@@ -1261,26 +1291,35 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
      * 128 Mi 25.1, 256 Mi 24.5 (FTN_WF_PATHS_M, in Mi paths).  If the GPU has less to give, the pass is halved (below). */
     uint32_t S = (uint32_t)std::max<size_t>(1, ((size_t)std::min<uint32_t>(knob("FTN_WF_PATHS_M", 256), 256u) << 20) / n_slots);
     S = std::min(S, total_samples);
-    int rc = wf_reserve(st, (size_t)S * n_slots);
-    while (rc == FTN_ERR_OUT_OF_MEMORY && S > 1) {            /* the wavefront does not fit next to what else lives on this GPU: smaller passes */
-        wf_free(st); (void)hipGetLastError();
-        S = (S + 1) / 2;
-        rc = wf_reserve(st, (size_t)S * n_slots);
-    }
-    if (rc) { wf_free(st); return rc; }
-    if ((rc = trace4_prepare(st, P.S))) return rc;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
     const bool dl_mode = P.integrator_kind != FTN_INTEGRATOR_PATH;          /* DirectLightingIntegrator / WhittedIntegrator: k_wf_shade_dl */
     const bool whitted = P.integrator_kind == FTN_INTEGRATOR_WHITTED;
+    const bool dl_tex = dl_mode && P.S.n_textures != 0;
+    uint32_t dl_levels = 0, dl_slots = 0;
     if (dl_mode) {
-        if (P.S.n_textures) { g_wf_err = "the wavefront pipeline runs DirectLightingIntegrator / WhittedIntegrator for scenes without textures"; return FTN_ERR_UNSUPPORTED; }
-        if (whitted && P.S.n_lights > WF_WH_MAX_LIGHTS) { g_wf_err = "the wavefront pipeline runs WhittedIntegrator for up to 4 lights"; return FTN_ERR_UNSUPPORTED; }
-        const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(P.max_depth, WF_DL_MAX)), slots = whitted ? std::max<uint32_t>(P.S.n_lights, 1u) : 1u;
-        if ((rc = wf_reserve_dl(st, st->cap_paths, levels, slots))) return rc;
-        st->W.dlA = (float4*)st->dl_mem[0]; st->W.dlB = (float4*)st->dl_mem[1]; st->W.whT = (float4*)st->dl_mem[2];
+        if (whitted && P.S.n_lights > WF_WH_MAX_LIGHTS) { g_wf_err = "the wavefront pipeline runs WhittedIntegrator for up to 32 lights (one bit per light in a path's pending-light word)"; return FTN_ERR_UNSUPPORTED; }
+        dl_levels = std::max<uint32_t>(1u, std::min<uint32_t>(P.max_depth, WF_DL_MAX)); dl_slots = whitted ? std::max<uint32_t>(P.S.n_lights, 1u) : 1u;
+        /* a shadow ray's queue entry is its slot p + l * n_paths, and bit 31 marks MIS rays: slots * paths stays below 2^31 */
+        const size_t cap = ((size_t)1 << 31) / std::max<uint32_t>(dl_slots, 2u) - 1u;
+        S = (uint32_t)std::max<size_t>(1, std::min<size_t>(S, cap / n_slots));
+        if ((size_t)n_slots > cap) { g_wf_err = "too many pixel slots for this many lights in one call: render the film in several tile ranges"; return FTN_ERR_UNSUPPORTED; }
     }
+    auto reserve = [&](uint32_t samples) -> int {
+        int r = wf_reserve(st, (size_t)samples * n_slots);
+        if (!r && dl_mode) r = wf_reserve_dl(st, st->cap_paths, dl_levels, dl_slots, dl_tex);
+        return r;
+    };
+    int rc = reserve(S);
+    while (rc == FTN_ERR_OUT_OF_MEMORY && S > 1) {            /* the wavefront does not fit next to what else lives on this GPU: smaller passes */
+        wf_free(st); wf_free_dl(st); (void)hipGetLastError();
+        S = (S + 1) / 2;
+        rc = reserve(S);
+    }
+    if (rc) { wf_free(st); wf_free_dl(st); return rc; }
+    if ((rc = trace4_prepare(st, P.S))) return rc;
+    if (dl_mode) { st->W.dlA = (float4*)st->dl_mem[0]; st->W.dlB = (float4*)st->dl_mem[1]; st->W.whT = (float4*)st->dl_mem[2]; st->W.dfd = (float4*)st->dl_mem[7]; }
     WfBuffers W = st->W;
-    if (dl_mode) { W.sh = (float4*)st->dl_mem[3]; W.occluded = (unsigned char*)st->dl_mem[4]; W.q_shadow = (uint32_t*)st->dl_mem[5]; }
+    if (dl_mode) { W.sh = (float4*)st->dl_mem[3]; W.occluded = (unsigned char*)st->dl_mem[4]; W.q_shadow = (uint32_t*)st->dl_mem[5]; W.q_exc_any = (uint32_t*)st->dl_mem[6]; }
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
@@ -1391,8 +1430,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 const bool tex = P.S.n_textures != 0;
                 const uint32_t first = it == 0 ? 1u : 0u;
                 if (dl_mode) {
-                    if (whitted) hipLaunchKernelGGL((k_wf_shade_dl<true>), sgrid, dim3(256), 0, stream, P, W, in_q);
-                    else hipLaunchKernelGGL((k_wf_shade_dl<false>), sgrid, dim3(256), 0, stream, P, W, in_q);
+                    if (whitted) { if (tex) hipLaunchKernelGGL((k_wf_shade_dl<true, true>), sgrid, dim3(256), 0, stream, P, W, in_q); else hipLaunchKernelGGL((k_wf_shade_dl<true, false>), sgrid, dim3(256), 0, stream, P, W, in_q); }
+                    else { if (tex) hipLaunchKernelGGL((k_wf_shade_dl<false, true>), sgrid, dim3(256), 0, stream, P, W, in_q); else hipLaunchKernelGGL((k_wf_shade_dl<false, false>), sgrid, dim3(256), 0, stream, P, W, in_q); }
                 } else if (!knob("FTN_SHADE_SPECIALISE", 1)) {
                     if (tex) hipLaunchKernelGGL((k_wf_shade<true, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu, first);
                     else hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu, first);

@@ -41,6 +41,9 @@ struct WfBuffers {
     /* DirectLightingIntegrator / WhittedIntegrator (k_wf_shade_dl): per-level terms of the nested product, level-major: dlA[d * n_paths + p] =
      * {local.rgb, pdf}, dlB = {f.rgb, |cos|}; whT[l * n_paths + p] = Whitted's term of light l (added if its shadow ray is unoccluded) */
     float4 *dlA, *dlB, *whT;
+    /* textured scenes: the ray differentials that follow the specular chain (integrator/mod.rs:58-84), SoA: dfd[k * n_paths + p], k = 0..2 =
+     * {rx_origin, rx_dir.x} {ry_origin, rx_dir.y} {ry_dir, rx_dir.z}; level 0 rebuilds the camera's from the sample key instead */
+    float4* dfd;
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
 

@@ -140,7 +140,7 @@ def check_recipe(gpu, orc_det, recipe, seed):
     cases = [(PathIntegrator.new(5, 1.0), RandomSampler(4, seed, indexed=True), WAVE), (PathIntegrator.new(5, 1.0), RandomSampler(4, seed, indexed=True), MEGA),
              (PathIntegrator.new(3, 0.5), RandomSampler(1, 0), MEGA), (DirectLightingIntegrator(3), RandomSampler(2, 0, indexed=True), MEGA),
              (WhittedIntegrator(3), RandomSampler(2, 0, indexed=True), MEGA),
-             # AUTO: the wavefront stages of the two integrators wherever the queues take the scene (no textures; Whitted: <= 4 lights), else the megakernel
+             # AUTO: the wavefront stages of the two integrators (textured scenes included; Whitted up to 32 lights), the megakernel otherwise
              (DirectLightingIntegrator(4), RandomSampler(2, seed, indexed=True), A.FTN_PIPELINE_AUTO), (WhittedIntegrator(4), RandomSampler(2, seed, indexed=True), A.FTN_PIPELINE_AUTO)]
     for integ, smp, pl in cases:
         px, st, err = render(gpu, *g, integ, smp, pl)

@@ -723,21 +723,28 @@ def test_direct_lighting_and_whitted_on_the_wavefront_pipeline(gpu, orc_det, sce
     assert np.array_equal(bits(auto[1]), bits(scenes.render(gpu, *make(gpu), integ, smp, backend_kwargs=dict(pipeline=WAVE))[1]))
 
 
-def test_wavefront_direct_lighting_limits(gpu):
-    """what the queues do not take is refused (explicit request) or left to the megakernel (AUTO): Whitted with more than four lights
-    (one shadow-ray slot per light and path); the reference's tile-serial sampler"""
-    def many_lights(be):
+def test_wavefront_direct_lighting_limits(gpu, orc_det):
+    """Whitted with many lights on the queues (one shadow-ray slot and one mask bit per light: up to 32), bit-equal to the oracle and the
+    megakernel; beyond 32 lights an explicit request is refused and AUTO leaves the scene to the megakernel; the reference's tile-serial
+    sampler is not taken by these stages."""
+    def many_lights(be, n):
         b, cam, res = scenes.cornell(be, res=32)
-        for k in range(4):
-            b.light_source("point", I=(1, 1, 1), from_=(0.1 * k, 0, 0.5))
+        for k in range(n):
+            b.light_source("point", I=(1 + 0.1 * k, 1, 1), from_=(0.07 * k - 0.5, 0.03 * k, 0.5))
         return b, cam, res
     smp = RandomSampler(2, 0, indexed=True)
+    for n in (4, 11, 31):                                        # + the Cornell box's area light: 5, 12, 32 lights
+        (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, lambda be: many_lights(be, n), WhittedIntegrator(3), smp, WAVE, "production")
+        assert_film_equal(px, pxo, st["spill_samples"], "Whitted, %d lights" % (n + 1))
+        assert st["rays_any"] == sto["rays_any"] and st["rays_closest"] == sto["rays_closest"]
+        m = scenes.render(gpu, *many_lights(gpu, n), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
+        assert np.array_equal(bits(px), bits(m[1]))
     with pytest.raises(FountainError) as e:
-        scenes.render(gpu, *many_lights(gpu), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))
+        scenes.render(gpu, *many_lights(gpu, 32), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))
     assert e.value.code == A.FTN_ERR_UNSUPPORTED
-    a = scenes.render(gpu, *many_lights(gpu), WhittedIntegrator(3), smp)                                       # AUTO -> megakernel
-    m = scenes.render(gpu, *many_lights(gpu), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
+    a = scenes.render(gpu, *many_lights(gpu, 32), WhittedIntegrator(3), smp)                                       # AUTO -> megakernel
+    m = scenes.render(gpu, *many_lights(gpu, 32), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
     assert np.array_equal(bits(a[1]), bits(m[1]))
-    scenes.render(gpu, *many_lights(gpu), DirectLightingIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))   # one light per hit: any number of lights
+    scenes.render(gpu, *many_lights(gpu, 40), DirectLightingIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))   # one light per hit: any number of lights
     with pytest.raises(FountainError):
         scenes.render(gpu, *scenes.cornell(gpu, res=32), DirectLightingIntegrator(3), RandomSampler(2, 0), backend_kwargs=dict(pipeline=WAVE))

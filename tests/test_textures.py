@@ -252,11 +252,14 @@ MEGA, WAVE = A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT
     ("path tile-serial", PathIntegrator.new(3, 1.0), RandomSampler(1, 0), MEGA),
     ("direct", DirectLightingIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA),
     ("whitted", WhittedIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA),
+    # the wavefront stages of the two integrators: the ray differentials follow the specular chain through WfBuffers::dfd (the mirror shows textured surfaces)
+    ("direct wavefront", DirectLightingIntegrator(4), RandomSampler(4, 0, indexed=True), WAVE),
+    ("whitted wavefront", WhittedIntegrator(4), RandomSampler(4, 0, indexed=True), WAVE),
 ])
 def test_textured_render_matches_oracle(gpu, orc_det, name, integ, sampler, pipeline):
     from test_gpu_parity import assert_film_equal, render_pair
     img = _img()
-    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, lambda be: textured_scene(be, img), integ, sampler, pipeline)
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, lambda be: textured_scene(be, img), integ, sampler, pipeline, "production" if name.endswith("wavefront") else "counting")
     assert_film_equal(px, pxo, st["spill_samples"], name)
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
     assert rgb.std() > 0.05                                  # not a blank frame
