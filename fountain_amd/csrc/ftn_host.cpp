@@ -1050,12 +1050,12 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING && id->kind != FTN_INTEGRATOR_WHITTED) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
     if (id->max_depth > 65535u) return fail(FTN_ERR_INVALID_ARGUMENT, "max_depth is a u16 in the reference (integrator/path.rs:14)");
     uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
-    /* the wavefront pipeline renders the indexed sampler; PathIntegrator always, DirectLightingIntegrator / WhittedIntegrator for scenes
-     * without textures (their texture differentials follow the specular chain: megakernel) and, Whitted, with at most 4 lights */
+    /* the wavefront pipeline renders the indexed sampler: PathIntegrator, DirectLightingIntegrator and WhittedIntegrator (the latter with at
+     * most 32 lights); the reference's tile-serial sampler and Whitted with more lights take the megakernel */
     const bool wf_ok = indexed && (id->kind != FTN_INTEGRATOR_WHITTED || s->d.n_lights <= 32u);      /* (Whitted: one bit per light in a path's pending-light word) */
     if (pipeline == FTN_PIPELINE_AUTO) pipeline = wf_ok ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
     if (pipeline == FTN_PIPELINE_WAVEFRONT && !wf_ok)
-        return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED; DirectLightingIntegrator / WhittedIntegrator only without textures (Whitted: up to 4 lights)");
+        return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED, WhittedIntegrator with up to 32 lights");
     const bool count = opt && opt->count_traffic;
     const bool count_production = opt && opt->count_traffic == 2;      /* tally the production configuration instead of the reference's walk */
 

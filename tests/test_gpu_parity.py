@@ -733,17 +733,18 @@ def test_wavefront_direct_lighting_limits(gpu, orc_det):
             b.light_source("point", I=(1 + 0.1 * k, 1, 1), from_=(0.07 * k - 0.5, 0.03 * k, 0.5))
         return b, cam, res
     smp = RandomSampler(2, 0, indexed=True)
-    for n in (4, 11, 31):                                        # + the Cornell box's area light: 5, 12, 32 lights
+    n_area = len(many_lights(gpu, 0)[0].create_scene().lights()[0])            # the Cornell box's emitter: one light per triangle
+    for n in (4, 11, 32 - n_area):                               # the last one: exactly 32 lights
         (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, lambda be: many_lights(be, n), WhittedIntegrator(3), smp, WAVE, "production")
-        assert_film_equal(px, pxo, st["spill_samples"], "Whitted, %d lights" % (n + 1))
+        assert_film_equal(px, pxo, st["spill_samples"], "Whitted, %d lights" % (n + n_area))
         assert st["rays_any"] == sto["rays_any"] and st["rays_closest"] == sto["rays_closest"]
         m = scenes.render(gpu, *many_lights(gpu, n), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
         assert np.array_equal(bits(px), bits(m[1]))
     with pytest.raises(FountainError) as e:
-        scenes.render(gpu, *many_lights(gpu, 32), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))
+        scenes.render(gpu, *many_lights(gpu, 33 - n_area), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))
     assert e.value.code == A.FTN_ERR_UNSUPPORTED
-    a = scenes.render(gpu, *many_lights(gpu, 32), WhittedIntegrator(3), smp)                                       # AUTO -> megakernel
-    m = scenes.render(gpu, *many_lights(gpu, 32), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
+    a = scenes.render(gpu, *many_lights(gpu, 33 - n_area), WhittedIntegrator(3), smp)                                       # AUTO -> megakernel
+    m = scenes.render(gpu, *many_lights(gpu, 33 - n_area), WhittedIntegrator(3), smp, backend_kwargs=dict(pipeline=MEGA))
     assert np.array_equal(bits(a[1]), bits(m[1]))
     scenes.render(gpu, *many_lights(gpu, 40), DirectLightingIntegrator(3), smp, backend_kwargs=dict(pipeline=WAVE))   # one light per hit: any number of lights
     with pytest.raises(FountainError):
