@@ -1050,12 +1050,15 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
     if (id->kind != FTN_INTEGRATOR_PATH && id->kind != FTN_INTEGRATOR_DIRECT_LIGHTING && id->kind != FTN_INTEGRATOR_WHITTED) return fail(FTN_ERR_INVALID_ARGUMENT, "unknown integrator kind");
     if (id->max_depth > 65535u) return fail(FTN_ERR_INVALID_ARGUMENT, "max_depth is a u16 in the reference (integrator/path.rs:14)");
     uint32_t pipeline = opt ? opt->pipeline : FTN_PIPELINE_AUTO;
-    /* the wavefront pipeline renders the indexed sampler: PathIntegrator, DirectLightingIntegrator and WhittedIntegrator (the latter with at
-     * most 32 lights); the reference's tile-serial sampler and Whitted with more lights take the megakernel */
-    const bool wf_ok = indexed && (id->kind != FTN_INTEGRATOR_WHITTED || s->d.n_lights <= 32u);      /* (Whitted: one bit per light in a path's pending-light word) */
-    if (pipeline == FTN_PIPELINE_AUTO) pipeline = wf_ok ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
+    /* the wavefront pipeline renders the indexed sampler for PathIntegrator, DirectLightingIntegrator and WhittedIntegrator (the latter with at
+     * most 32 lights: one bit per light in a path's pending-light word), and the reference's tile-serial sampler for PathIntegrator (one
+     * path per tile in flight: wavefront_render_serial).  AUTO takes it for the tile-serial sampler once the call has enough tiles to fill
+     * the queues (below, when the tile list is known); everything else is the megakernel's */
+    const bool wf_ok = indexed ? (id->kind != FTN_INTEGRATOR_WHITTED || s->d.n_lights <= 32u) : id->kind == FTN_INTEGRATOR_PATH;
+    const bool auto_pipeline = pipeline == FTN_PIPELINE_AUTO;
+    if (auto_pipeline) pipeline = wf_ok ? FTN_PIPELINE_WAVEFRONT : FTN_PIPELINE_MEGAKERNEL;
     if (pipeline == FTN_PIPELINE_WAVEFRONT && !wf_ok)
-        return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders FTN_SAMPLER_INDEXED, WhittedIntegrator with up to 32 lights");
+        return fail(FTN_ERR_UNSUPPORTED, "the wavefront pipeline renders PathIntegrator with either sampler, DirectLightingIntegrator / WhittedIntegrator (up to 32 lights) with FTN_SAMPLER_INDEXED");
     const bool count = opt && opt->count_traffic;
     const bool count_production = opt && opt->count_traffic == 2;      /* tally the production configuration instead of the reference's walk */
 
@@ -1072,6 +1075,9 @@ int ftn_render_device(const ftn_scene* cs, const ftn_camera_desc* cam, const ftn
         uint32_t off = 0; for (DTile& t : s->sel) { t.valid_off = off; t._pad = 0; off += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0)); }
     }
     std::vector<DTile>& sel = s->sel;
+    /* tile-serial: a round of the queue pipeline costs ~0.3 ms whatever it holds, a megakernel lane per tile diverges from its 63 neighbours:
+     * the queues win once a call has a few thousand tiles (measured: profiles/r03), a handful of tiles is the megakernel's */
+    if (auto_pipeline && !indexed && pipeline == FTN_PIPELINE_WAVEFRONT && sel.size() < 2048) pipeline = FTN_PIPELINE_MEGAKERNEL;
 
     RenderParams P; memset(&P, 0, sizeof(P));
     P.S = s->d;

@@ -524,13 +524,19 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                         if (TEX && material_is_textured(S, mat)) {
                             /* Texture::evaluate(si).  The differentials are the CAMERA ray's, handed on unchanged by the path integrator
                              * (path.rs:73): rebuilt here from the path's sample key instead of being carried in the path state. */
-                            const uint32_t slot = p / W.samples, sidx = p % W.samples;
-                            const DTile tile = P.tiles[slot >> 8];
-                            const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
-                            Rng crng; crng.seed(indexed_key(P.seed, px, py, W.first_sample + sidx));
-                            const V2 j = crng.next2(); const V2 p_film((float)px + j.x, (float)py + j.y); const V2 p_lens = crng.next2(); const float time_u = crng.next();
-                            const DRay cam = camera_ray(P.C, p_film, p_lens, time_u);
-                            const DRayDiff rd = camera_ray_diff(P.C, p_film, p_lens, cam, 1.0f / sqrtf((float)P.spp));
+                            DRayDiff rd;
+                            if (W.serial) {                      /* (no sample key in the tile-serial stream: k_wf_serial_advance stored them) */
+                                const float4 d0 = W.dfd[p], d1 = W.dfd[(size_t)W.n_paths + p], d2 = W.dfd[2 * (size_t)W.n_paths + p];
+                                rd.has = true; rd.rxo = V3(d0.x, d0.y, d0.z); rd.ryo = V3(d1.x, d1.y, d1.z); rd.ryd = V3(d2.x, d2.y, d2.z); rd.rxd = V3(d0.w, d1.w, d2.w);
+                            } else {
+                                const uint32_t slot = p / W.samples, sidx = p % W.samples;
+                                const DTile tile = P.tiles[slot >> 8];
+                                const int px = tile.x0 + (int)(slot & 15u), py = tile.y0 + (int)((slot >> 4) & 15u);
+                                Rng crng; crng.seed(indexed_key(P.seed, px, py, W.first_sample + sidx));
+                                const V2 j = crng.next2(); const V2 p_film((float)px + j.x, (float)py + j.y); const V2 p_lens = crng.next2(); const float time_u = crng.next();
+                                const DRay cam = camera_ray(P.C, p_film, p_lens, time_u);
+                                rd = camera_ray_diff(P.C, p_film, p_lens, cam, 1.0f / sqrtf((float)P.spp));
+                            }
                             DSIX ex; DSI s2; make_interaction(S, h, ray0, &s2, &ex);
                             const DTexDiffs td = compute_tex_diffs(si.hit.p, si.hit.n, ex.dpdu, ex.dpdv, rd);
                             mloc = material_resolve(S, mat, ex.uv, td); mp = &mloc;
@@ -603,7 +609,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                             } else alive = false;
                         }
                     }
-                    if (alive) { W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3); }      /* (an ended path draws nothing more) */
+                    if (alive || W.serial) { W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3); }      /* (an ended path draws nothing more; the tile-serial stream goes on behind it) */
                 }
                 ps = (ps & ~(PS_BOUNCE_MASK | PS_ALIVE)) | (bounces & PS_BOUNCE_MASK) | (alive ? PS_ALIVE : 0u);
                 push_active = alive || (ps & PS_DIRECT);        /* finished paths with a pending direct term come back once */
@@ -611,6 +617,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 W.rad[p] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word));
                 active_entry = p | (alive ? (bounces >= P.max_depth ? WF_Q_DEPTH : 0u) : WF_Q_FIN);
             }
+            if (W.serial && !push_active) W.ser_retired[p] = 1;      /* nothing pending: k_wf_serial_advance takes it from here */
         }
         {
             const bool pred[6] = {push_active, push_closest, push_mis, push_shadow, push_mis_any, push_mis_any};
@@ -901,11 +908,14 @@ __global__ void k_wf_reset(WfBuffers W, int mode, int in_q, DevStats* stats) {
         for (int i = 32; i < 56; i++) W.counters[CTR(i)] = 0;                                /* exception queues of the four-box kernels: counts and heads */
     } else if (mode == 2) {                                                                  /* before classify */
         for (int i = 0; i < WF_NCLASS; i++) W.cls[CTR(i)] = 0;
+    } else if (mode == 3) {                                                                  /* tile-serial pass: the queues start empty, k_wf_serial_advance fills them */
+        for (int i = 0; i < 64; i++) W.counters[CTR(i)] = 0;
     }
 }
 
 /* ------------------------------------------------------------------ accumulate: add_sample_to_tile in sample order */
 struct FilmCtxW { int crop[4]; int tpb[4]; int sb[4]; float radius[2]; };
+#define WF_OWN_SERIAL (-2147483647 - 1)
 __device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 p_film, Rgb L, int own_x, int own_y, float4* acc, uint32_t* spill, uint32_t* bc_writes) {
     float pdx = p_film.x - 0.5f, pdy = p_film.y - 0.5f;
     int p0x = f2i_sat(ceilf(pdx - F.radius[0])), p0y = f2i_sat(ceilf(pdy - F.radius[1]));
@@ -919,6 +929,11 @@ __device__ inline void wf_film_add(const RenderParams& P, const FilmCtxW& F, V2 
             touched++;
             if (x == own_x && y == own_y) { acc->x += contrib.r; acc->y += contrib.g; acc->z += contrib.b; acc->w += 1.0f; continue; }
             const bool in_tile = x >= F.sb[0] && x < F.sb[2] && y >= F.sb[1] && y < F.sb[3];
+            if (in_tile && own_x == WF_OWN_SERIAL) {         /* tile-serial: the tile's one writer adds in-tile samples straight into A, in stream order (film_add, ftn_kernels.hip) */
+                float4* a = P.accA + ((size_t)(y - F.crop[1]) * width + (size_t)(x - F.crop[0]));
+                float4 v = *a; v.x += contrib.r; v.y += contrib.g; v.z += contrib.b; v.w += 1.0f; *a = v;
+                continue;
+            }
             float* f = reinterpret_cast<float*>((in_tile ? P.accB : P.accC) + ((size_t)(y - F.crop[1]) * width + (size_t)(x - F.crop[0])));
             atomicAdd(f + 0, contrib.r); atomicAdd(f + 1, contrib.g); atomicAdd(f + 2, contrib.b); atomicAdd(f + 3, 1.0f);
             (*bc_writes)++;
@@ -980,6 +995,74 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(RenderParams P, WfBuffers
     if (err) atomicCAS(&P.stats->error, 0, err);
 }
 
+/* ------------------------------------------------------------------ the reference's RandomSampler on the queues (render_tile, integrator/mod.rs:229-281, with
+ * sampler.clone_with_seed(tile_id), random.rs:61-67): one thread per tile.  init: seeds the tile's stream and starts its first camera sample.
+ * Afterwards, once per bounce round: a tile whose path was marked retired adds that radiance to the film -- samples of a tile in stream
+ * order, in-tile pixels by this single writer as k_render_serial does -- and draws the next camera sample (pixel by pixel, row-major,
+ * spp samples each) from the stream position the finished path left. */
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_wf_serial_advance(RenderParams P, WfBuffers W, int out_q, int init) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    bool push = false;
+    uint32_t spill = 0, bc = 0, cam = 0; int err = 0;
+    if (t < W.n_paths) {
+        const DTile tile = P.tiles[t];
+        const uint32_t tw = (uint32_t)(tile.x1 - tile.x0), npix = tw * (uint32_t)(tile.y1 - tile.y0);
+        Rng rng; uint2 cur = make_uint2(0u, 0u); bool start = false;
+        if (init) { rng.seed(tile.tile_id); start = npix > 0u && P.spp > 0u; W.ser_retired[t] = 0; }
+        else if (W.ser_retired[t]) {
+            W.ser_retired[t] = 0;
+            { const ulonglong2 a = W.rng01[t], b = W.rng23[t]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
+            cur = W.ser_cursor[t];
+            const float4 l = W.rad[t]; const float2 pf = W.ser_pfilm[t];
+            Rgb L(l.x, l.y, l.z);
+            if (L.has_nans()) err = FTN_ERR_NAN_RADIANCE;
+            FilmCtxW F;
+            for (int i = 0; i < 4; i++) F.crop[i] = P.crop[i];
+            F.sb[0] = tile.x0; F.sb[1] = tile.y0; F.sb[2] = tile.x1; F.sb[3] = tile.y1; F.radius[0] = P.radius[0]; F.radius[1] = P.radius[1];
+            const int p0x = f2i_sat(ceilf((float)tile.x0 - 0.5f - P.radius[0])), p0y = f2i_sat(ceilf((float)tile.y0 - 0.5f - P.radius[1]));
+            const int p1x = f2i_sat(ceilf((float)tile.x1 - 0.5f + P.radius[0] + 1.0f)), p1y = f2i_sat(ceilf((float)tile.y1 - 0.5f - P.radius[1] + 1.0f));
+            F.tpb[0] = max(p0x, P.crop[0]); F.tpb[1] = max(p0y, P.crop[1]); F.tpb[2] = min(p1x, P.crop[2]); F.tpb[3] = min(p1y, P.crop[3]);
+            float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            wf_film_add(P, F, V2(pf.x, pf.y), L, WF_OWN_SERIAL, 0, &none, &spill, &bc);
+            cam = 1;
+            if (++cur.y == P.spp) { cur.y = 0; cur.x++; }
+            start = cur.x < npix;
+        }
+        if (start) {
+            const int px = tile.x0 + (int)(cur.x % tw), py = tile.y0 + (int)(cur.x / tw);
+            const V2 j = rng.next2();
+            const V2 p_film((float)px + j.x, (float)py + j.y);
+            const V2 p_lens = rng.next2();
+            const float time_u = rng.next();
+            const DRay ray = camera_ray(P.C, p_film, p_lens, time_u);
+            W.ray[2 * (size_t)t] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+            W.ray[2 * (size_t)t + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.t_max);
+            W.beta[t] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE));
+            W.rad[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            W.rng01[t] = make_ulonglong2(rng.s0, rng.s1); W.rng23[t] = make_ulonglong2(rng.s2, rng.s3);
+            W.ser_cursor[t] = cur; W.ser_pfilm[t] = make_float2(p_film.x, p_film.y);
+            if (TEX) {                                           /* generate_ray_differential + scale_differentials (mod.rs:252-254) */
+                const DRayDiff rd = camera_ray_diff(P.C, p_film, p_lens, ray, 1.0f / sqrtf((float)P.spp));
+                W.dfd[t] = make_float4(rd.rxo.x, rd.rxo.y, rd.rxo.z, rd.rxd.x); W.dfd[(size_t)W.n_paths + t] = make_float4(rd.ryo.x, rd.ryo.y, rd.ryo.z, rd.rxd.y);
+                W.dfd[2 * (size_t)W.n_paths + t] = make_float4(rd.ryd.x, rd.ryd.y, rd.ryd.z, rd.rxd.z);
+            }
+            push = true;
+        }
+    }
+    {
+        const bool pred[2] = {push, push};
+        const uint32_t val[2] = {t | (P.max_depth == 0 ? WF_Q_DEPTH : 0u), t};
+        uint32_t* const qs[2] = {W.q_active[out_q], W.q_closest};
+        uint32_t* const cs[2] = {&W.counters[CTR(out_q == 0 ? 0 : 1)], &W.counters[CTR(2)]};
+        block_push<2>(pred, val, qs, cs);
+    }
+    if (cam) atomicAdd(&P.stats->camera_samples, (unsigned long long)cam);
+    if (spill) atomicAdd(&P.stats->spill_samples, (unsigned long long)spill);
+    if (bc) atomicAdd(&P.stats->bc_writes, (unsigned long long)bc);
+    if (err) atomicCAS(&P.stats->error, 0, err);
+}
+
 /* ================================================================== host driver */
 static thread_local std::string g_wf_err;
 const char* wavefront_error() { return g_wf_err.c_str(); }
@@ -1022,6 +1105,7 @@ struct WavefrontState {
     /* buffers of the direct-lighting / Whitted mode (grow-only): level terms, and shadow-ray records / results / queue sized for one ray per light */
     void* dl_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dl_paths = 0; uint32_t dl_levels = 0, dl_slots = 0; bool dl_tex = false;
     Trace4Plan t4; bool t4_on = false, t4_dual = false;
+    void* ser_mem[4] = {nullptr, nullptr, nullptr, nullptr}; size_t ser_paths = 0; bool ser_tex = false;      /* tile-serial sampler on the queues: cursor, film position, retired flag, differentials */
     void* t4_spill_c = nullptr; void* t4_spill_a = nullptr; size_t t4_spill_c_bytes = 0, t4_spill_a_bytes = 0;
 };
 #define WF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_wf_err = std::string(#expr ": ") + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE; } } while (0)
@@ -1037,6 +1121,7 @@ void wavefront_destroy(WavefrontState* st) {
     if (st->side) (void)hipStreamDestroy(st->side);
     if (st->drain_sig) (void)hipFree(st->drain_sig);
     for (void* m : st->dl_mem) if (m) (void)hipFree(m);
+    for (void* m : st->ser_mem) if (m) (void)hipFree(m);
     if (st->t4_spill_c) (void)hipFree(st->t4_spill_c);
     if (st->t4_spill_a) (void)hipFree(st->t4_spill_a);
     if (st->host_counters) (void)hipHostFree(st->host_counters);
@@ -1273,6 +1358,84 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
     return FTN_OK;
 }
 
+/* ------------------------------------------------------------------ FTN_SAMPLER_TILE_SERIAL through the queues (PathIntegrator).
+ * The reference's RandomSampler is one serial stream per tile, so a tile has ONE camera sample in flight; with T tiles the wavefront holds
+ * T paths at mixed depths.  A round = the two traces, classify, the shade launches (the kernels of the indexed pipeline, unchanged) and
+ * k_wf_serial_advance, which retires finished paths into the film and starts the tiles' next samples; the host polls the active count
+ * once per round.  Same stream, same film sums as k_render_serial -- but the traversal and the shading of a round run convergent instead
+ * of diverging inside one megakernel lane per tile. */
+static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, uint32_t n_tiles, bool count, bool count_production, hipStream_t stream, WavefrontTimes* times) {
+    int rc = wf_reserve(st, (size_t)std::max<uint32_t>(n_tiles, 256u));
+    if (rc) { wf_free(st); return rc; }
+    const bool tex = P.S.n_textures != 0;
+    if (n_tiles > st->ser_paths || (tex && !st->ser_tex)) {
+        for (void*& m : st->ser_mem) { if (m) (void)hipFree(m); m = nullptr; }
+        st->ser_paths = 0;
+        WF_TRY(hipMalloc(&st->ser_mem[0], (size_t)n_tiles * sizeof(uint2)));
+        WF_TRY(hipMalloc(&st->ser_mem[1], (size_t)n_tiles * sizeof(float2)));
+        WF_TRY(hipMalloc(&st->ser_mem[2], (size_t)n_tiles));
+        if (tex) WF_TRY(hipMalloc(&st->ser_mem[3], 3 * (size_t)n_tiles * sizeof(float4)));
+        st->ser_paths = n_tiles; st->ser_tex = tex;
+    }
+    if ((rc = trace4_prepare(st, P.S))) return rc;
+    WfBuffers W = st->W;
+    W.serial = 1; W.ser_cursor = (uint2*)st->ser_mem[0]; W.ser_pfilm = (float2*)st->ser_mem[1]; W.ser_retired = (unsigned char*)st->ser_mem[2]; W.dfd = (float4*)st->ser_mem[3];
+    W.n_slots = 0; W.samples = 1; W.n_paths = n_tiles; W.first_sample = 0; W.seg_cap = (uint32_t)st->cap_paths; W.valid_per_sample = 0;
+    const int count_mode = count ? (count_production ? 2 : 1) : 0;
+    W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
+    const bool spheres = P.S.n_spheres != 0;
+    const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
+    const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    const unsigned tg = std::min<unsigned>((unsigned)st->n_cu * blocks_per_cu, (2 * n_tiles + 255) / 256);
+    const dim3 pgrid((n_tiles + 255) / 256), sgrid(std::min<unsigned>((unsigned)st->n_cu * 8u, (n_tiles + 255) / 256));
+    const bool env = P.S.env_only && knob("FTN_SHADE_ENV", 1);
+    hipEvent_t e0 = st->ev[0], e1 = st->ev[1];
+    (void)hipEventRecord(e0, stream);
+    hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 3, 0, P.stats);
+    if (tex) hipLaunchKernelGGL((k_wf_serial_advance<true>), pgrid, dim3(256), 0, stream, P, W, 0, 1); else hipLaunchKernelGGL((k_wf_serial_advance<false>), pgrid, dim3(256), 0, stream, P, W, 0, 1);
+    int in_q = 0; unsigned long long rounds = 0, trace_launches = 0;
+    /* every round ends at least one bounce of every live tile; a sample takes at most max_depth + 3 rounds, plus null-material pass-throughs */
+    const uint64_t max_rounds = 256u * (uint64_t)std::max<uint32_t>(P.spp, 1u) * ((uint64_t)P.max_depth + 4u + (1u << 12));
+    for (uint64_t it = 0; it < max_rounds; it++) {
+        launch_trace(st, false, count_mode, spheres, tg, lds, stream, P, W, W.q_closest, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * n_tiles);
+        trace_launches++;
+        if (it > 0) launch_trace(st, true, count_mode, spheres, tg, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * n_tiles);
+        hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
+        hipLaunchKernelGGL(k_wf_classify, sgrid, dim3(256), 0, stream, P, W, in_q);
+        hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
+#define FTN_SH2(T, M, E, mask) hipLaunchKernelGGL((k_wf_shade<T, M, E>), sgrid, dim3(256), 0, stream, P, W, in_q, mask, 0u)
+#define FTN_SH(M, mask) do { if (tex) { if (env) FTN_SH2(true, M, true, mask); else FTN_SH2(true, M, false, mask); } \
+                             else { if (env) FTN_SH2(false, M, true, mask); else FTN_SH2(false, M, false, mask); } } while (0)
+        if (!knob("FTN_SHADE_SPECIALISE", 1)) FTN_SH(-1, 0xffu);
+        else {
+            FTN_SH(-2, 0x83u);
+            if (P.S.material_types & 1u) FTN_SH(0, 1u << 2);
+            if (P.S.material_types & 2u) FTN_SH(1, 1u << 3);
+            if (P.S.material_types & 4u) FTN_SH(2, 1u << 4);
+            if (P.S.material_types & 8u) FTN_SH(3, 1u << 5);
+            if (P.S.material_types & 16u) FTN_SH(4, 1u << 6);
+        }
+#undef FTN_SH2
+#undef FTN_SH
+        if (tex) hipLaunchKernelGGL((k_wf_serial_advance<true>), pgrid, dim3(256), 0, stream, P, W, in_q ^ 1, 0); else hipLaunchKernelGGL((k_wf_serial_advance<false>), pgrid, dim3(256), 0, stream, P, W, in_q ^ 1, 0);
+        in_q ^= 1; rounds++;
+        WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        WF_TRY(hipStreamSynchronize(stream));
+        if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
+    }
+    (void)hipEventRecord(e1, stream);
+    WF_TRY(hipEventSynchronize(e1));
+    WF_TRY(hipGetLastError());
+    if (times) {
+        float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1);
+        memset(times, 0, sizeof(*times));
+        times->trace_launches = trace_launches; times->mis_any_rays = W.mis_any ? st->host_counters[CTR(10)] : 0;
+        times->shade_launches = rounds;
+        (void)ms;
+    }
+    return FTN_OK;
+}
+
 int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::vector<DTile>& tiles, bool count, hipStream_t stream, WavefrontTimes* times,
                      bool count_production) {
     knobs_begin();
@@ -1284,6 +1447,10 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     const uint32_t total_samples = P.last_sample - P.first_sample;
     if (total_samples == 0) return FTN_OK;
     if (tiles.size() > ((size_t)1 << 20)) { g_wf_err = "more than 2^20 tiles (2^28 pixel slots) in one call: render the film in several tile ranges"; return FTN_ERR_UNSUPPORTED; }
+    if (P.sampler_kind != FTN_SAMPLER_INDEXED) {
+        if (P.integrator_kind != FTN_INTEGRATOR_PATH) { g_wf_err = "the tile-serial sampler runs on the queues for PathIntegrator"; return FTN_ERR_UNSUPPORTED; }
+        return wavefront_render_serial(st, P, (uint32_t)tiles.size(), count, count_production, stream, times);
+    }
     /* samples per pass: up to 256 Mi paths in flight (~88 GB of path state and queues out of 288 GB; the ids, queue indices and sort
      * counts are 32-bit: 2^28 paths is also their limit).  Bigger wavefronts are faster per ray: the sorted queues hold more rays per
      * cell of space (more lanes of a wave share node records) and every launch's drain -- about 0.5 ms whatever its size -- is paid

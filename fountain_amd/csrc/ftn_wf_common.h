@@ -44,6 +44,13 @@ struct WfBuffers {
     /* textured scenes: the ray differentials that follow the specular chain (integrator/mod.rs:58-84), SoA: dfd[k * n_paths + p], k = 0..2 =
      * {rx_origin, rx_dir.x} {ry_origin, rx_dir.y} {ry_dir, rx_dir.z}; level 0 rebuilds the camera's from the sample key instead */
     float4* dfd;
+    /* FTN_SAMPLER_TILE_SERIAL on the queues (the reference's RandomSampler: ONE Xoshiro stream per tile, random.rs:61-67): path id = tile,
+     * one camera sample per tile in flight; a path that has nothing pending any more is marked by the shade kernels and k_wf_serial_advance
+     * adds it to the film and starts the tile's next sample from the stream position the path left */
+    uint32_t serial;
+    uint2* ser_cursor;          /* per tile: {pixel index inside the tile (row-major over its extent), sample index} of the sample in flight */
+    float2* ser_pfilm;          /* ... and its film position */
+    unsigned char* ser_retired;
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
 

@@ -122,11 +122,16 @@ def test_empty_scene(gpu):
     ("path_no_rr", PathIntegrator.new(10, 0.0), 2.0, 0.001),
     ("directlighting", DirectLightingIntegrator(3), 1.5, 1e-5)])
 def test_furnace_reference_sampler(gpu, orc_det, name, integ, expected, eps):
-    """The three assertions of tests/furnace.rs with the reference's per-tile RandomSampler stream (one serial lane per tile)."""
+    """The three assertions of tests/furnace.rs with the reference's per-tile RandomSampler stream: one serial lane per tile in the
+    megakernel, and -- PathIntegrator -- one path per tile on the wavefront queues (wavefront_render_serial), production kernels."""
     (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, scenes.furnace, integ, RandomSampler(128, 0), MEGA)
     assert np.abs(rgb - expected).max() <= eps
     assert np.array_equal(bits(px), bits(pxo))
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"]
+    if name.startswith("path"):
+        (rgbw, pxw, stw), _ = render_pair(gpu, orc_det, scenes.furnace, integ, RandomSampler(128, 0), WAVE, "production")
+        assert np.array_equal(bits(pxw), bits(pxo)) and np.abs(rgbw - expected).max() <= eps
+        assert stw["rays_closest"] == sto["rays_closest"] and stw["rays_any"] == sto["rays_any"] and stw["camera_samples"] == sto["camera_samples"]
 
 
 @pytest.mark.parametrize("kernels", KERNELS)
@@ -188,6 +193,22 @@ def test_render_vs_libm_oracle(gpu, orc, scene):
     same = (bits(px) == bits(pxo)).all(axis=-1).mean()
     rmse = float(np.sqrt(((rgb.astype(np.float64) - rgbo) ** 2).mean()))
     assert same >= 0.5 and rmse <= 1e-4, (same, rmse)
+
+
+@pytest.mark.parametrize("kernels", KERNELS)
+@pytest.mark.parametrize("scene", ["cornell", "materials", "cubes27", "cube_env"])
+def test_tile_serial_sampler_on_the_wavefront_queues(gpu, orc_det, scene, kernels):
+    """The reference's RandomSampler (one Xoshiro stream per 16 x 16 tile, random.rs:61-67) through the queue pipeline: one path per tile
+    in flight, retired paths added to the film in stream order, the next camera sample drawn from where the finished path left the
+    stream.  Bit-equal to the oracle (and hence to the megakernel's serial lanes), clipped edge tiles and thin-lens cameras included."""
+    make, spp = SCENES[scene]
+    smp = RandomSampler(3, 0)
+    (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, make, PathIntegrator.new(5, 1.0), smp, WAVE, kernels)
+    assert_film_equal(px, pxo, st["spill_samples"], scene + ", tile-serial on the queues")
+    for k in ("rays_closest", "rays_any", "camera_samples", "spill_samples") + (("nodes_visited", "prims_tested") if kernels == "counting" else ()):
+        assert st[k] == sto[k], (k, st[k], sto[k])
+    mega = scenes.render(gpu, *make(gpu), PathIntegrator.new(5, 1.0), smp, backend_kwargs=dict(pipeline=MEGA))
+    assert_film_equal(px, mega[1], st["spill_samples"], scene + ", queues vs megakernel")
 
 
 def test_tile_serial_reference_stream(gpu, orc_det):

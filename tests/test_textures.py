@@ -250,6 +250,7 @@ MEGA, WAVE = A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT
     ("path mega", PathIntegrator.new(5, 1.0), RandomSampler(4, 0, indexed=True), MEGA),
     ("path wavefront", PathIntegrator.new(5, 1.0), RandomSampler(4, 0, indexed=True), WAVE),
     ("path tile-serial", PathIntegrator.new(3, 1.0), RandomSampler(1, 0), MEGA),
+    ("path tile-serial wavefront", PathIntegrator.new(3, 1.0), RandomSampler(2, 0), WAVE),
     ("direct", DirectLightingIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA),
     ("whitted", WhittedIntegrator(4), RandomSampler(4, 0, indexed=True), MEGA),
     # the wavefront stages of the two integrators: the ray differentials follow the specular chain through WfBuffers::dfd (the mirror shows textured surfaces)

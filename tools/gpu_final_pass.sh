@@ -1,9 +1,9 @@
 set -e
 mkdir -p gpurun_out/fin
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/fin/gpu_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q -s > gpurun_out/fin/gpu_tests.log 2>&1
 tail -2 gpurun_out/fin/gpu_tests.log
-timeout -k 10 900 python tools/make_traffic_json.py profiles/r02 > gpurun_out/fin/traffic.log 2>&1
-cp profiles/r02/traffic.json gpurun_out/fin/traffic.json
+timeout -k 10 900 python tools/make_traffic_json.py profiles/r03 > gpurun_out/fin/traffic.log 2>&1
+cp profiles/r03/traffic.json gpurun_out/fin/traffic.json
 timeout -k 10 600 python bench.py --steps 10 --warmup 2 > gpurun_out/fin/bench.json 2> gpurun_out/fin/bench.err
 tail -c 600 gpurun_out/fin/bench.json
 ROOT=$PWD
