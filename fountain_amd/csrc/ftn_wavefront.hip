@@ -1105,7 +1105,7 @@ struct WavefrontState {
     /* buffers of the direct-lighting / Whitted mode (grow-only): level terms, and shadow-ray records / results / queue sized for one ray per light */
     void* dl_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dl_paths = 0; uint32_t dl_levels = 0, dl_slots = 0; bool dl_tex = false;
     Trace4Plan t4; bool t4_on = false, t4_dual = false;
-    void* ser_mem[4] = {nullptr, nullptr, nullptr, nullptr}; size_t ser_paths = 0; bool ser_tex = false;      /* tile-serial sampler on the queues: cursor, film position, retired flag, differentials */
+    void* ser_mem[4] = {nullptr, nullptr, nullptr, nullptr}; size_t ser_paths = 0; bool ser_tex = false; uint32_t* ser_host = nullptr;      /* tile-serial sampler on the queues: cursor, film position, retired flag, differentials */
     void* t4_spill_c = nullptr; void* t4_spill_a = nullptr; size_t t4_spill_c_bytes = 0, t4_spill_a_bytes = 0;
 };
 #define WF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_wf_err = std::string(#expr ": ") + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? FTN_ERR_OUT_OF_MEMORY : FTN_ERR_NO_DEVICE; } } while (0)
@@ -1125,6 +1125,7 @@ void wavefront_destroy(WavefrontState* st) {
     if (st->t4_spill_c) (void)hipFree(st->t4_spill_c);
     if (st->t4_spill_a) (void)hipFree(st->t4_spill_a);
     if (st->host_counters) (void)hipHostFree(st->host_counters);
+    if (st->ser_host) (void)hipHostFree(st->ser_host);
     delete st;
 }
 template <class T> static int wf_alloc(WavefrontState* st, T** p, size_t n) {
@@ -1363,7 +1364,9 @@ int wavefront_trace_batch(WavefrontState** state, const DScene& S, uint32_t stac
  * T paths at mixed depths.  A round = the two traces, classify, the shade launches (the kernels of the indexed pipeline, unchanged) and
  * k_wf_serial_advance, which retires finished paths into the film and starts the tiles' next samples; the host polls the active count
  * once per round.  Same stream, same film sums as k_render_serial -- but the traversal and the shading of a round run convergent instead
- * of diverging inside one megakernel lane per tile. */
+ * of diverging inside one megakernel lane per tile.  Measured on the config-5 scene (65,536 tiles, 1 spp): 1110 rounds of 0.51 ms = 94 Mrays/s
+ * against the megakernel's 35.  A round is as long as its longest walk (latency, not throughput: the GPU holds 5 x these rays in flight),
+ * so cutting the tiles into groups that run side by side multiplies the rounds without shortening any (profiles/r03/d_*: not kept). */
 static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, uint32_t n_tiles, bool count, bool count_production, hipStream_t stream, WavefrontTimes* times) {
     int rc = wf_reserve(st, (size_t)std::max<uint32_t>(n_tiles, 256u));
     if (rc) { wf_free(st); return rc; }
@@ -1394,12 +1397,22 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
     hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 3, 0, P.stats);
     if (tex) hipLaunchKernelGGL((k_wf_serial_advance<true>), pgrid, dim3(256), 0, stream, P, W, 0, 1); else hipLaunchKernelGGL((k_wf_serial_advance<false>), pgrid, dim3(256), 0, stream, P, W, 0, 1);
     int in_q = 0; unsigned long long rounds = 0, trace_launches = 0;
+    if (!st->ser_host) WF_TRY(hipHostMalloc((void**)&st->ser_host, 2 * 16 * 32 * sizeof(uint32_t)));
+    int polled_q[2] = {0, 0}; uint32_t* last = st->ser_host;
+    const bool side_ok = st->side != nullptr && knob("FTN_WF_OVERLAP", 2) != 0 && getenv("ROCPROF_COUNTER_COLLECTION") == nullptr;
     /* every round ends at least one bounce of every live tile; a sample takes at most max_depth + 3 rounds, plus null-material pass-throughs */
     const uint64_t max_rounds = 256u * (uint64_t)std::max<uint32_t>(P.spp, 1u) * ((uint64_t)P.max_depth + 4u + (1u << 12));
     for (uint64_t it = 0; it < max_rounds; it++) {
+        /* the two traces of a round side by side: with one ray per tile a launch is as long as its longest walk (0.25 - 0.35 ms for 65 k
+         * rays that the GPU could trace in 0.02 ms), and the two launches are independent */
+        const bool beside = it > 0 && side_ok;
+        if (beside) { WF_TRY(hipEventRecord(st->ev_ready, stream)); WF_TRY(hipStreamWaitEvent(st->side, st->ev_ready, 0));
+                      launch_trace(st, true, count_mode, spheres, tg, lds, st->side, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * n_tiles);
+                      WF_TRY(hipEventRecord(st->ev_side, st->side)); }
         launch_trace(st, false, count_mode, spheres, tg, lds, stream, P, W, W.q_closest, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * n_tiles);
         trace_launches++;
-        if (it > 0) launch_trace(st, true, count_mode, spheres, tg, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * n_tiles);
+        if (it > 0 && !beside) launch_trace(st, true, count_mode, spheres, tg, lds, stream, P, W, W.q_shadow, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * n_tiles);
+        if (beside) WF_TRY(hipStreamWaitEvent(stream, st->ev_side, 0));
         hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 2, in_q, P.stats);
         hipLaunchKernelGGL(k_wf_classify, sgrid, dim3(256), 0, stream, P, W, in_q);
         hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, W, 1, in_q, P.stats);
@@ -1419,10 +1432,21 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
 #undef FTN_SH
         if (tex) hipLaunchKernelGGL((k_wf_serial_advance<true>), pgrid, dim3(256), 0, stream, P, W, in_q ^ 1, 0); else hipLaunchKernelGGL((k_wf_serial_advance<false>), pgrid, dim3(256), 0, stream, P, W, in_q ^ 1, 0);
         in_q ^= 1; rounds++;
-        WF_TRY(hipMemcpyAsync(st->host_counters, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        WF_TRY(hipStreamSynchronize(stream));
-        if (st->host_counters[CTR(in_q == 0 ? 0 : 1)] == 0) break;
+        /* the active count of this round is read while the NEXT round is already queued (no bubble on the GPU between rounds); the loop
+         * therefore ends one round late, with a round over empty queues */
+        uint32_t* hb = st->ser_host + (it & 1u) * 16u * 32u;
+        WF_TRY(hipMemcpyAsync(hb, W.counters, 16 * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        WF_TRY(hipEventRecord(st->ev[2 + (it & 1u)], stream));
+        polled_q[it & 1u] = in_q;
+        if (it >= 1) {
+            const uint32_t k = (uint32_t)((it - 1) & 1u);
+            WF_TRY(hipEventSynchronize(st->ev[2 + k]));
+            if (st->ser_host[k * 16u * 32u + CTR(polled_q[k] == 0 ? 0 : 1)] == 0) { last = hb; break; }
+        }
+        last = hb;
     }
+    WF_TRY(hipStreamSynchronize(stream));
+    memcpy(st->host_counters, last, 16 * 32 * sizeof(uint32_t));
     (void)hipEventRecord(e1, stream);
     WF_TRY(hipEventSynchronize(e1));
     WF_TRY(hipGetLastError());

@@ -211,6 +211,14 @@ def test_tile_serial_sampler_on_the_wavefront_queues(gpu, orc_det, scene, kernel
     assert_film_equal(px, mega[1], st["spill_samples"], scene + ", queues vs megakernel")
 
 
+def test_tile_serial_queues_many_tiles(gpu, orc_det):
+    """625 tiles (the last row and column clipped to 16 x 0 ... pixels by the 400 x 400 film): more tiles than one shade workgroup holds"""
+    make = lambda be: scenes.cornell(be, res=400)
+    (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, make, PathIntegrator.new(3, 1.0), RandomSampler(1, 0), WAVE, "production")
+    assert_film_equal(px, pxo, st["spill_samples"], "625 tiles, tile-serial on the queues")
+    assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and st["camera_samples"] == 400 * 400
+
+
 def test_tile_serial_reference_stream(gpu, orc_det):
     """The reference's exact RandomSampler (one Xoshiro256+ stream per 16x16 tile) on a triangle + sphere scene"""
     (rgb, px, st), (_, pxo, sto) = render_pair(gpu, orc_det, lambda be: scenes.cornell(be, res=32), PathIntegrator.new(5, 1.0), RandomSampler(2, 0), MEGA)
