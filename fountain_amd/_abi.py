@@ -141,7 +141,7 @@ class ftn_stats(C.Structure):
 
 
 class ftn_scene_memory(C.Structure):
-    _fields_ = [(k, c_u64) for k in ("nodes", "quad", "fat", "geom", "srec", "indexed_attributes", "prim_class", "lights", "textures", "other", "total")]
+    _fields_ = [(k, c_u64) for k in ("nodes", "quad", "oct", "fat", "geom", "srec", "indexed_attributes", "prim_class", "lights", "textures", "other", "total")]
 
 
 FTN_ABI_VERSION = 3          # include/fountain_hip.h; Backend() refuses a product library that reports another one
@@ -151,7 +151,7 @@ SIZES = {
     "ftn_transform": 128, "ftn_pixel": 16, "ftn_bvh_node": 32, "ftn_prim": 16, "ftn_mesh": 20,
     "ftn_sphere": 288, "ftn_material": 48, "ftn_light": 160, "ftn_envmap": 16, "ftn_camera_desc": 296,
     "ftn_film_desc": 32, "ftn_sampler_desc": 24, "ftn_integrator_desc": 16, "ftn_tile_range": 16,
-    "ftn_render_options": 16, "ftn_stats": 152, "ftn_scene_memory": 88, "ftn_texture": 48, "ftn_image": 24, "ftn_material_textures": 32,
+    "ftn_render_options": 16, "ftn_stats": 152, "ftn_scene_memory": 96, "ftn_texture": 48, "ftn_image": 24, "ftn_material_textures": 32,
 }
 
 # Every function the header declares (name -> None); used by the symbol-export test.
@@ -162,7 +162,7 @@ DECLARED_FUNCTIONS = [
     "ftn_transform_swaps_handedness", "ftn_transform_points", "ftn_transform_normals",
     "ftn_sphere_init", "ftn_camera_perspective", "ftn_film_init",
     "ftn_film_sample_bounds", "ftn_film_tile_count", "ftn_film_resolve", "ftn_scene_create",
-    "ftn_scene_destroy", "ftn_bvh_build", "ftn_bvh_quads", "ftn_scene_info", "ftn_scene_get_nodes", "ftn_scene_get_lights",
+    "ftn_scene_destroy", "ftn_bvh_build", "ftn_bvh_quads", "ftn_bvh_octs", "ftn_scene_info", "ftn_scene_get_nodes", "ftn_scene_get_lights",
     "ftn_intersect", "ftn_intersect_test", "ftn_intersect_full", "ftn_render", "ftn_render_device",
     "ftn_last_error", "ftn_device_count", "ftn_version", "ftn_abi_version", "ftn_scene_memory_info", "ftn_test_math",
     "ftn_pbrt_load", "ftn_pbrt_destroy", "ftn_pbrt_scene", "ftn_pbrt_camera", "ftn_pbrt_film",

@@ -98,6 +98,10 @@ struct DScene {
      * built).  quad_stack_bound: upper bound of the entries a walk can have pending. */
     const float4* quad;
     uint32_t n_quads, quad_stack_bound;
+    /* a second tree over the same leaves for Scene::intersect_test only (build_octs, ftn_host.cpp; ftn_trace8.hip): 128-byte records of up
+     * to eight children with outward-rounded 8-bit boxes, exact leaf boxes (oct_xbox: the leaves whose box is not their one triangle's) */
+    const uint4* oct; const float4* oct_xbox;
+    uint32_t n_octs, oct_stack_bound;
     /* shading class of every primitive (k_wf_classify, ftn_wavefront.hip): 2 + material type, 7 for a primitive without material.  One
      * byte per primitive -- cache resident where prim_info (32 bytes per primitive) is not.  Never NULL for a scene with primitives. */
     const unsigned char* prim_class;

@@ -422,6 +422,116 @@ static void build_quads(const std::vector<ftn_bvh_node>& nodes, QuadBvh* out) {
     out->ok = true;
 }
 
+/* ------------------------------------------------------------------ eight-box occlusion records (DScene::oct): a SECOND tree over the same leaves, for
+ * Scene::intersect_test only (k_wf_trace8_any, ftn_trace8.hip).
+ * intersect_test (bvh.rs:217-266) never shrinks t_max and returns a boolean: a ray is occluded iff SOME leaf's own box passes the slab test
+ * and one of its primitives passes its test (the boxes of the leaf's ancestors pass whenever the leaf's does -- the monotonicity argument of
+ * build_quads).  Which interior boxes are tested on the way is therefore free, as long as every leaf whose box the ray enters is reached:
+ * interior boxes may be LARGER than the reference's.  A record holds up to eight children of a collapsed subtree (an interior node's
+ * children, the largest one replaced by its own children until eight are there) with their boxes quantised to 8 bits per plane on a
+ * per-record grid (origin = the subtree's min corner, a power-of-two step per axis), rounded outwards: 96 bytes decide up to three
+ * levels -- a walk fetches ~40 % fewer records than four-box records and half the bytes.  Leaves are tested exactly in the kernel: a
+ * single triangle's leaf box is the min / max of its vertices (checked here against the reference's node), any other leaf carries its
+ * exact box in `xbox`.
+ * Record (32 words): [0..2] origin, [3] step exponents (biased, one byte per axis), [4..11] child links -- byte offset of the child's
+ * record | 0, leaf: bit 31 | first primitive, leaf with an explicit box: bit 31 | bit 30 | index into xbox, empty: 0xffffffff --,
+ * [12..23] planes, one byte per child: lo.x[8] hi.x[8] lo.y[8] hi.y[8] lo.z[8] hi.z[8]; [24..31] unused (one 128-byte line per record). */
+struct OctBvh { std::vector<uint32_t> rec; std::vector<float4> xbox; uint32_t n_records = 0, stack_bound = 0; bool ok = false; };
+static void build_octs(const std::vector<ftn_bvh_node>& nodes, const std::vector<float4>& geom, OctBvh* out) {
+    out->rec.clear(); out->xbox.clear(); out->n_records = 0; out->stack_bound = 0; out->ok = false;
+    if (nodes.empty() || nodes[0].is_leaf) return;                                /* (a single leaf: the four-box path handles it) */
+    auto area = [&](uint32_t i) { const ftn_bvh_node& n = nodes[i]; const double dx = (double)n.bmax[0] - n.bmin[0], dy = (double)n.bmax[1] - n.bmin[1], dz = (double)n.bmax[2] - n.bmin[2]; return 2.0 * (dx * dy + dy * dz + dz * dx); };
+    struct Rec { uint32_t root; uint32_t child[8]; int n; };
+    std::vector<Rec> recs; std::vector<uint32_t> rec_of(nodes.size(), 0xffffffffu);
+    {   /* pass 1: collapse, records numbered in DFS order */
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty()) {
+            const uint32_t r = todo.back(); todo.pop_back();
+            Rec R; R.root = r; R.n = 2; R.child[0] = r + 1u; R.child[1] = nodes[r].idx;
+            for (;;) {
+                if (R.n == 8) break;
+                int best = -1; double ba = -1.0;
+                for (int k = 0; k < R.n; k++) if (!nodes[R.child[k]].is_leaf) { const double a = area(R.child[k]); if (a > ba) { ba = a; best = k; } }
+                if (best < 0) break;
+                const uint32_t c = R.child[best];
+                R.child[best] = c + 1u; R.child[R.n++] = nodes[c].idx;
+            }
+            rec_of[r] = (uint32_t)recs.size(); recs.push_back(R);
+            for (int k = R.n - 1; k >= 0; k--) if (!nodes[R.child[k]].is_leaf) todo.push_back(R.child[k]);
+        }
+    }
+    if (recs.size() >= (1u << 24)) return;                                       /* links are byte offsets below 2^31 */
+    out->rec.assign((size_t)32 * recs.size(), 0u);
+    std::vector<uint32_t> bound(recs.size(), 0);
+    for (size_t q = recs.size(); q-- > 0;) {
+        const Rec& R = recs[q];
+        const ftn_bvh_node& root = nodes[R.root];
+        uint32_t* W = &out->rec[(size_t)32 * q];
+        uint32_t ebits[3]; float step[3];
+        for (int a = 0; a < 3; a++) {
+            /* the smallest power-of-two step that covers the subtree's extent with 255 steps -- one more if the outward rounding of a child
+             * plane would not fit */
+            const double ext = (double)root.bmax[a] - (double)root.bmin[a];
+            int e = ext > 0.0 ? (int)ceil(log2(ext / 255.0)) : -126;
+            if (e < -126) e = -126;
+            for (;; e++) {
+                bool fits = true;
+                const float st = ldexpf(1.0f, e);
+                for (int k = 0; k < R.n && fits; k++) {
+                    const ftn_bvh_node& c = nodes[R.child[k]];
+                    const double qh = ceil(((double)c.bmax[a] - (double)root.bmin[a]) / (double)st);
+                    if (qh > 254.0) fits = false;                                 /* (one step of slack for the adjustment below) */
+                }
+                if (fits || e >= 126) break;
+            }
+            step[a] = ldexpf(1.0f, e); ebits[a] = (uint32_t)(e + 127);
+            memcpy(&W[a], &root.bmin[a], 4);
+        }
+        W[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
+        uint32_t deepest = 0;
+        for (int k = 0; k < 8; k++) {
+            uint32_t link = 0xffffffffu; uint32_t qb[6] = {255u, 0u, 255u, 0u, 255u, 0u};
+            if (k < R.n) {
+                const uint32_t ci = R.child[k]; const ftn_bvh_node& c = nodes[ci];
+                for (int a = 0; a < 3; a++) {
+                    /* decoded plane = origin + q * step, exactly as the kernel's bounds (real-number inequality: lo_dec <= lo, hi_dec >= hi) */
+                    const double o = (double)root.bmin[a], stp = (double)step[a];
+                    double ql = floor(((double)c.bmin[a] - o) / stp), qh = ceil(((double)c.bmax[a] - o) / stp);
+                    while (ql > 0.0 && o + ql * stp > (double)c.bmin[a]) ql -= 1.0;
+                    while (o + qh * stp < (double)c.bmax[a]) qh += 1.0;
+                    if (ql < 0.0) ql = 0.0;
+                    if (qh > 255.0) qh = 255.0;                                   /* (cannot happen: the step was chosen with slack) */
+                    qb[2 * a] = (uint32_t)ql; qb[2 * a + 1] = (uint32_t)qh;
+                }
+                if (!c.is_leaf) { link = rec_of[ci] * 128u; deepest = std::max(deepest, bound[rec_of[ci]]); }
+                else {
+                    bool implicit_box = c.n_prims == 1 && !geom.empty();
+                    if (implicit_box) {                                           /* a single triangle whose node box is the min / max of its vertices */
+                        const float4 g0 = geom[(size_t)FTN_GS * c.idx], g1 = geom[(size_t)FTN_GS * c.idx + 1], g2 = geom[(size_t)FTN_GS * c.idx + 2];
+                        if (ftn_det::f2u(g0.w) & GF_KIND_SPHERE) implicit_box = false;
+                        else {
+                            const float lo[3] = {std::min(std::min(g0.x, g1.x), g2.x), std::min(std::min(g0.y, g1.y), g2.y), std::min(std::min(g0.z, g1.z), g2.z)};
+                            const float hi[3] = {std::max(std::max(g0.x, g1.x), g2.x), std::max(std::max(g0.y, g1.y), g2.y), std::max(std::max(g0.z, g1.z), g2.z)};
+                            for (int a = 0; a < 3; a++) if (ftn_det::f2u(lo[a]) != ftn_det::f2u(c.bmin[a]) || ftn_det::f2u(hi[a]) != ftn_det::f2u(c.bmax[a])) implicit_box = false;
+                        }
+                    }
+                    if (implicit_box) link = 0x80000000u | c.idx;
+                    else {
+                        link = 0xc0000000u | (uint32_t)(out->xbox.size() / 2);
+                        out->xbox.push_back(make_float4(c.bmin[0], c.bmin[1], c.bmin[2], ftn_det::u2f(c.idx)));
+                        out->xbox.push_back(make_float4(c.bmax[0], c.bmax[1], c.bmax[2], 0.0f));
+                    }
+                }
+            }
+            W[4 + k] = link;
+            for (int j = 0; j < 6; j++) W[12 + 2 * j + (k >> 2)] |= qb[j] << (8 * (k & 3));
+        }
+        bound[q] = (uint32_t)(R.n - 1) + deepest;
+    }
+    if (out->xbox.size() / 2 >= (1u << 30) || nodes.size() >= (1u << 30)) return;
+    out->n_records = (uint32_t)recs.size(); out->stack_bound = bound[0]; out->ok = true;
+}
+
 static int bvh_default_threads() {
     int cores = (int)std::thread::hardware_concurrency();
 #ifdef __linux__
@@ -624,7 +734,7 @@ struct ftn_scene {
     int device = 0;
     HostScene host;
     DScene d; uint32_t stack_entries = 1;
-    DevBuf<float4> nodes, geom, fat, srec, quad; DevBuf<uint4> prim_info; DevBuf<float> N, UV, T; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
+    DevBuf<float4> nodes, geom, fat, srec, quad, oct_xbox; DevBuf<uint4> prim_info, oct; DevBuf<float> N, UV, T; DevBuf<DSphere> spheres; DevBuf<ftn_material> materials; DevBuf<DLight> lights;
     DevBuf<uint32_t> inf_lights; DevBuf<unsigned char> prim_class; std::vector<DevBuf<float>> misc; std::vector<DevBuf<float4>> misc4;
     DevBuf<ftn_texture> textures; DevBuf<ftn_material_textures> mtex; DevBuf<DImage> images; DevBuf<float4> texels;
     /* render work buffers (grow-only, reused across calls) */
@@ -633,7 +743,7 @@ struct ftn_scene {
     WavefrontState* wf = nullptr;
     std::vector<DTile> sel; int32_t tile_key[10] = {0};
     ~ftn_scene() {
-        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); prim_info.release(); N.release(); UV.release(); T.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release(); prim_class.release();
+        nodes.release(); geom.release(); fat.release(); srec.release(); quad.release(); oct.release(); oct_xbox.release(); prim_info.release(); N.release(); UV.release(); T.release(); spheres.release(); materials.release(); lights.release(); inf_lights.release(); prim_class.release();
         for (auto& b : misc) b.release();
         for (auto& b : misc4) b.release();
         textures.release(); mtex.release(); images.release(); texels.release();
@@ -719,6 +829,20 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if (qb.ok && qb.n_records) {
                 if ((rc = sc->quad.upload(reinterpret_cast<const float4*>(qb.rec.data()), (size_t)8 * qb.n_records))) return rc;
                 n_quads = qb.n_records; quad_bound = qb.stack_bound;
+            }
+        }
+    }
+    /* eight-box occlusion records (DScene::oct): triangle-only scenes with four-box records (the kernel hands its exceptional rays to the
+     * same fallback).  FTN_OCT=0: not built (k_wf_trace4_any_dual traces the shadow rays) */
+    uint32_t n_octs = 0, oct_bound = 0;
+    {
+        const char* knob = getenv("FTN_OCT");
+        if ((!knob || atoi(knob) != 0) && n_quads != 0 && d->n_spheres == 0) {
+            OctBvh ob; build_octs(hs.nodes, geom, &ob);
+            if (ob.ok && ob.n_records) {
+                if ((rc = sc->oct.upload(reinterpret_cast<const uint4*>(ob.rec.data()), (size_t)8 * ob.n_records))) return rc;
+                if (!ob.xbox.empty() && (rc = sc->oct_xbox.upload(ob.xbox.data(), ob.xbox.size()))) return rc;
+                n_octs = ob.n_records; oct_bound = ob.stack_bound;
             }
         }
     }
@@ -862,6 +986,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
     D.srec = sc->srec.p; D.prim_class = sc->prim_class.p;
     D.quad = sc->quad.p; D.n_quads = n_quads; D.quad_stack_bound = quad_bound;
+    D.oct = sc->oct.p; D.oct_xbox = sc->oct_xbox.p; D.n_octs = n_octs; D.oct_stack_bound = oct_bound;
     D.fat = sc->fat.p; D.n_fat = n_fat; D.root_is_leaf = (!hs.nodes.empty() && hs.nodes[0].is_leaf) ? 1u : 0u;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmin[k]; D.root_hi[k] = hs.nodes.empty() ? 0.0f : hs.nodes[0].bmax[k]; }
     if (lights.size() == 1 && lights[0].kind == LK_INFINITE) { D.env_only = 1; D.env0 = lights[0]; }
@@ -940,6 +1065,20 @@ int ftn_bvh_quads(const ftn_bvh_node* nodes, uint32_t n_nodes, float* records_ou
     return FTN_OK;
 }
 
+int ftn_bvh_octs(const ftn_bvh_node* nodes, uint32_t n_nodes, uint32_t* records_out, uint32_t* n_records_out, uint32_t* stack_bound_out, float* xbox_out, uint32_t* n_xbox_out) {
+    if (!nodes && n_nodes) return fail(FTN_ERR_INVALID_ARGUMENT, "null nodes");
+    std::vector<ftn_bvh_node> v(nodes, nodes + n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) if (!v[i].is_leaf && (v[i].idx <= i + 1 || v[i].idx >= n_nodes || v[i].axis > 2)) return fail(FTN_ERR_INVALID_ARGUMENT, "not a flattened BVH (bvh.rs:133-158)");
+    OctBvh ob; build_octs(v, std::vector<float4>(), &ob);       /* (no vertex data here: every leaf gets an explicit box) */
+    if (!ob.ok) return fail(FTN_ERR_UNSUPPORTED, "no interior node, or more than 2^24 eight-box records");
+    if (records_out) memcpy(records_out, ob.rec.data(), ob.rec.size() * sizeof(uint32_t));
+    if (n_records_out) *n_records_out = ob.n_records;
+    if (stack_bound_out) *stack_bound_out = ob.stack_bound;
+    if (xbox_out) memcpy(xbox_out, ob.xbox.data(), ob.xbox.size() * sizeof(float4));
+    if (n_xbox_out) *n_xbox_out = (uint32_t)(ob.xbox.size() / 2);
+    return FTN_OK;
+}
+
 int ftn_scene_create(const ftn_scene_desc* d, int device, ftn_scene** out) {
     if (!out) return fail(FTN_ERR_INVALID_ARGUMENT, "null output");
     int rc = set_device(device); if (rc) return rc;
@@ -963,6 +1102,7 @@ int ftn_scene_info(const ftn_scene* s, uint32_t* n_nodes, uint32_t* n_prims, uin
 int ftn_scene_memory_info(const ftn_scene* s, ftn_scene_memory* m) {
     if (!s || !m) return fail(FTN_ERR_INVALID_ARGUMENT, "null scene / output");
     memset(m, 0, sizeof(*m));
+    m->oct = s->oct.n * sizeof(uint4) + s->oct_xbox.n * sizeof(float4);
     m->nodes = s->nodes.n * sizeof(float4); m->quad = s->quad.n * sizeof(float4); m->fat = s->fat.n * sizeof(float4); m->geom = s->geom.n * sizeof(float4);
     m->srec = s->srec.n * sizeof(float4); m->indexed_attributes = s->prim_info.n * sizeof(uint4) + (s->N.n + s->UV.n + s->T.n) * sizeof(float);
     m->prim_class = s->prim_class.n;
@@ -971,7 +1111,7 @@ int ftn_scene_memory_info(const ftn_scene* s, ftn_scene_memory* m) {
     for (const auto& b : s->misc4) m->lights += b.n * sizeof(float4);
     m->textures = s->textures.n * sizeof(ftn_texture) + s->mtex.n * sizeof(ftn_material_textures) + s->images.n * sizeof(DImage) + s->texels.n * sizeof(float4);
     m->other = s->spheres.n * sizeof(DSphere) + s->materials.n * sizeof(ftn_material) + s->stats.n * sizeof(DevStats);
-    m->total = m->nodes + m->quad + m->fat + m->geom + m->srec + m->indexed_attributes + m->prim_class + m->lights + m->textures + m->other;
+    m->total = m->oct + m->nodes + m->quad + m->fat + m->geom + m->srec + m->indexed_attributes + m->prim_class + m->lights + m->textures + m->other;
     return FTN_OK;
 }
 int ftn_scene_get_nodes(const ftn_scene* s, ftn_bvh_node* nodes, uint32_t* order) {

@@ -552,10 +552,185 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any_dual(DScene S, WfBuffers 
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
 }
 
+/* ------------------------------------------------------------------ any hit over eight-box occlusion records (k_wf_trace8_any; DScene::oct, build_octs in ftn_host.cpp)
+ * intersect_test returns a boolean and never shrinks t_max: a ray is occluded iff some LEAF's own box passes the slab test and one of the
+ * leaf's primitives passes its test -- the interior boxes on the way only have to let every such leaf be reached, so they may be larger
+ * than the reference's.  The records hold up to eight children with 8-bit planes on a per-record grid, rounded outwards by the builder
+ * (decoded plane = origin + q * step with lo_dec <= lo and hi_dec >= hi as real numbers); the kernel's test of a decoded box is
+ *     t = q * (step / d) + (origin - o) / d          one fused multiply-add per plane, near / far plane picked by the sign of d,
+ * pushed outwards by m = (|(origin - o) / d| + 255 |step / d|) * 2^-20 -- four times the rounding error of this expression plus that of
+ * the reference's own (lo - o) * (1 / d), so the test passes whenever the reference's test of ANY box inside the decoded one passes (the
+ * far side is also scaled by 1 + 4 gamma(3) >= the reference's 1 + 2 gamma(3)).  A leaf is then tested exactly: Bounds3f::intersect_test
+ * on the leaf's true box (the min / max of a single triangle's vertices, or the explicit box of `oct_xbox`), then the triangle test.
+ * Rays whose 1/d or o/d are outside the range where these bounds hold (|1/d| > 2^60, |o| > 2^40) join the exceptional rays in the queue
+ * of the reference-order kernel.  Same scheduling as k_wf_trace4_any: persistent workgroups, XCD queue slices, LDS stack with a global
+ * spill area, record steps and leaf steps as separate convergent bodies.  ~12 records per ray instead of 20 four-box records. */
+enum : uint32_t { T8_IDLE = 0, T8_NODE = 1, T8_LEAF = 2, T8_LEAF_IN = 3 /* inside a leaf of several primitives whose box has passed */ };
+#define T8_XBOX 0x40000000u
+__device__ inline bool ray_out_of_range8(float ox, float oy, float oz, float ix, float iy, float iz) {
+    const float big_i = 1.152921504606846976e18f /* 2^60 */, big_o = 1.099511627776e12f /* 2^40 */;
+    return !(fabsf(ix) <= big_i && fabsf(iy) <= big_i && fabsf(iz) <= big_i && fabsf(ox) <= big_o && fabsf(oy) <= big_o && fabsf(oz) <= big_o);
+}
+struct T8Axis { float a, bn, bf; uint32_t n03, n47, f03, f47; };
+/* per record and axis: the two constants of the plane expression, the outward margin folded into the offsets, near / far byte rows by sign */
+__device__ inline T8Axis t8_axis(float org, uint32_t ebyte, float o, float inv, uint32_t lo03, uint32_t lo47, uint32_t hi03, uint32_t hi47) {
+    T8Axis A;
+    const float step = __uint_as_float(ebyte << 23);
+    A.a = step * inv;
+    const float b = (org - o) * inv;
+    const float m = (fabsf(b) + 255.0f * fabsf(A.a)) * 9.5367431640625e-07f;
+    A.bn = b - m; A.bf = b + m;
+    const bool neg = inv < 0.0f;
+    A.n03 = neg ? hi03 : lo03; A.n47 = neg ? hi47 : lo47; A.f03 = neg ? lo03 : hi03; A.f47 = neg ? lo47 : hi47;
+    return A;
+}
+#define T8_BYTE(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
+/* child c of the record: conservative entry / exit distances */
+#define T8_CHILD(c, t0v, t1v) \
+    { const uint32_t kx_ = (c) & 3; \
+      const float nx_ = fmaf(T8_BYTE((c) < 4 ? X.n03 : X.n47, kx_), X.a, X.bn), ny_ = fmaf(T8_BYTE((c) < 4 ? Y.n03 : Y.n47, kx_), Y.a, Y.bn), nz_ = fmaf(T8_BYTE((c) < 4 ? Z.n03 : Z.n47, kx_), Z.a, Z.bn); \
+      const float fx_ = fmaf(T8_BYTE((c) < 4 ? X.f03 : X.f47, kx_), X.a, X.bf), fy_ = fmaf(T8_BYTE((c) < 4 ? Y.f03 : Y.f47, kx_), Y.a, Y.bf), fz_ = fmaf(T8_BYTE((c) < 4 ? Z.f03 : Z.f47, kx_), Z.a, Z.bf); \
+      t0v = fmax_(fmax_(fmax_(0.0f, nx_), ny_), nz_); t1v = fmin_(t_max, fmin_(fmin_(fx_, fy_), fz_) * k2); }
+
+template <bool CHECK, int POLICY>
+__device__ __forceinline__ void t8_any_step(const DScene& S, T4Stack<uint32_t>& St, T4Lane& L, V3 o, V3 inv, float t_max) {
+    const uint4* rec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.oct) + L.cur);
+    const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+    const float k2 = 1.0f + 4.0f * gamma_n(3);
+    const T8Axis X = t8_axis(__uint_as_float(r0.x), r0.w & 0xffu, o.x, inv.x, r3.x, r3.y, r3.z, r3.w);
+    const T8Axis Y = t8_axis(__uint_as_float(r0.y), (r0.w >> 8) & 0xffu, o.y, inv.y, r4.x, r4.y, r4.z, r4.w);
+    const T8Axis Z = t8_axis(__uint_as_float(r0.z), (r0.w >> 16) & 0xffu, o.z, inv.z, r5.x, r5.y, r5.z, r5.w);
+    float a0, a1, b0, b1, c0, c1, d0, d1, e0, e1, f0, f1, g0, g1, h0, h1;
+    T8_CHILD(0, a0, a1) T8_CHILD(1, b0, b1) T8_CHILD(2, c0, c1) T8_CHILD(3, d0, d1) T8_CHILD(4, e0, e1) T8_CHILD(5, f0, f1) T8_CHILD(6, g0, g1) T8_CHILD(7, h0, h1)
+    const uint32_t la = r1.x, lb = r1.y, lc = r1.z, ld = r1.w, le = r2.x, lf = r2.y, lg = r2.z, lh = r2.w;
+    const bool ha = !(a0 > a1) && la != T4_NONE, hb = !(b0 > b1) && lb != T4_NONE, hc = !(c0 > c1) && lc != T4_NONE, hd = !(d0 > d1) && ld != T4_NONE;
+    const bool he = !(e0 > e1) && le != T4_NONE, hf = !(f0 > f1) && lf != T4_NONE, hg = !(g0 > g1) && lg != T4_NONE, hh = !(h0 > h1) && lh != T4_NONE;
+    uint32_t next = T4_NONE;
+    if (POLICY == 1) {
+        /* the child whose (decoded) box the ray stays in longest first: the order that ended blocked rays soonest over four-box records */
+        const float sa = ha ? a1 - a0 : -1.0f, sb = hb ? b1 - b0 : -1.0f, sc = hc ? c1 - c0 : -1.0f, sd = hd ? d1 - d0 : -1.0f;
+        const float se = he ? e1 - e0 : -1.0f, sf = hf ? f1 - f0 : -1.0f, sg = hg ? g1 - g0 : -1.0f, sh = hh ? h1 - h0 : -1.0f;
+        const float best = fmaxf(fmaxf(fmaxf(sa, sb), fmaxf(sc, sd)), fmaxf(fmaxf(se, sf), fmaxf(sg, sh)));
+        bool taken = !(best >= 0.0f);                             /* nothing entered: nothing to take */
+#define T8_PICK(hx, sx, lx) { const bool me_ = hx && !taken && sx == best; if (me_) { next = lx; taken = true; } else if (hx) St.template push<CHECK>(lx); }
+        T8_PICK(ha, sa, la) T8_PICK(hb, sb, lb) T8_PICK(hc, sc, lc) T8_PICK(hd, sd, ld) T8_PICK(he, se, le) T8_PICK(hf, sf, lf) T8_PICK(hg, sg, lg) T8_PICK(hh, sh, lh)
+#undef T8_PICK
+    } else {
+        bool taken = false;
+#define T8_PICK(hx, lx) { if (hx) { if (!taken) { next = lx; taken = true; } else St.template push<CHECK>(lx); } }
+        T8_PICK(ha, la) T8_PICK(hb, lb) T8_PICK(hc, lc) T8_PICK(hd, ld) T8_PICK(he, le) T8_PICK(hf, lf) T8_PICK(hg, lg) T8_PICK(hh, lh)
+#undef T8_PICK
+    }
+    if (next == T4_NONE) {
+        if (St.empty()) { L.finish = true; return; }
+        next = St.template pop<CHECK>();
+    }
+    if (next >> 31) { L.lp = next & 0x7fffffffu; L.mode = T8_LEAF; } else L.cur = next;
+}
+
+template <bool COUNT, int BURST, int POLICY>
+__global__ void __launch_bounds__(256) k_wf_trace8_any(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head, DevStats* stats,
+                                                       uint32_t refill, uint32_t leaf_batch, uint32_t chunk_max, uint32_t lds_entries, uint32_t* __restrict__ spill, uint32_t spill_levels) {
+    T4Stack<uint32_t> St;
+    St.base = lds_stack1 + threadIdx.x;
+    St.lim = St.base + 256u * lds_entries; St.sp = St.base; St.spill = spill; St.spill_levels = spill_levels;
+    St.n_lanes = (size_t)gridDim.x * 256u; St.gl = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const bool st_tiny = lds_entries < 7u;                         /* a record step pushes at most seven entries */
+    uint32_t* const st_soft = st_tiny ? St.base : St.lim - 7 * 256;
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = lane_id();
+    unsigned long long n_rec = 0, n_prim = 0;
+    unsigned long long occ[7] = {0, 0, 0, 0, 0, 0, 0};
+    T4Lane L; L.mode = T8_IDLE; L.cur = 0; L.lp = 0; L.finish = false;
+    WaveQueue Q; wq_init(Q, count, chunk_max);
+    uint32_t rid = 0;
+    RaySetup R; R.o = V3(0.0f, 0.0f, 0.0f); R.inv = R.o; R.dorig = R.o; R.t_max = 0.0f; R.neg24 = 0; R.kz = 0; R.sx = R.sy = R.sz = 0.0f;
+    bool found = false;
+    const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f), rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
+    for (;;) {
+        const unsigned long long idle = __ballot(L.mode == T8_IDLE);
+        if (!Q.exhausted && (uint32_t)__popcll(idle) >= refill) {
+            const uint32_t need = (uint32_t)__popcll(idle);
+            (void)wq_refill(Q, count, head, lane);
+            const uint32_t avail = Q.chunk_end - Q.chunk_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            bool hand_back = false; uint32_t q_entry = 0;
+            if (COUNT) { occ[5]++; occ[6] += need < avail ? need : avail; }
+            if (L.mode == T8_IDLE && rank < avail) {
+                float4 a, b;
+                q_entry = queue[Q.chunk_next + rank];
+                load_queued_ray<true>(W, q_entry, &a, &b, &rid);
+                ray_setup<false>(R, a, b);
+                St.sp = St.base; L.cur = 0; found = false;
+                if (ray_is_exceptional(R.o.x, R.o.y, R.o.z, R.inv.x, R.inv.y, R.inv.z) || ray_out_of_range8(R.o.x, R.o.y, R.o.z, R.inv.x, R.inv.y, R.inv.z)) hand_back = true;
+                else if (!slab_test(rlo, rhi, R.o, R.inv, R.t_max)) W.occluded[rid] = 0;       /* the root's own box (bvh.rs:228 at node 0) */
+                else L.mode = T8_NODE;
+            }
+            if (__ballot(hand_back) != 0) wave_push(hand_back, q_entry, W.q_exc_any, &W.counters[CTR(33)]);
+            Q.chunk_next += (need < avail ? need : avail);
+        }
+        const unsigned long long m_node = __ballot(L.mode == T8_NODE), m_leaf = __ballot(L.mode >= T8_LEAF);
+        if ((m_node | m_leaf) == 0) { if (Q.exhausted) break; else continue; }
+        L.finish = false;
+        if (COUNT) occ[0]++;
+        if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
+#pragma unroll
+            for (int burst = 0; burst < BURST; burst++) {
+                const bool on = L.mode == T8_NODE && !L.finish;
+                if (COUNT && on) n_rec++;
+                if (COUNT) { const unsigned long long m_on = __ballot(on); if (m_on) { occ[1]++; occ[2] += (unsigned long long)__popcll(m_on); } }
+                if (__builtin_expect(__ballot(on && (st_tiny || St.sp > st_soft)) == 0, 1)) { if (on) t8_any_step<false, POLICY>(S, St, L, R.o, R.inv, R.t_max); }
+                else if (on) t8_any_step<true, POLICY>(S, St, L, R.o, R.inv, R.t_max);
+            }
+        } else {
+            /* ---- leaf step: the leaf's exact box (on entering the leaf), then one primitive */
+            if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
+            if (L.mode >= T8_LEAF) {
+                const bool entering = L.mode == T8_LEAF;
+                uint32_t prim = L.lp & 0x3fffffffu;
+                float4 x0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), x1 = x0;
+                const bool explicit_box = entering && (L.lp & T8_XBOX);
+                if (explicit_box) { x0 = S.oct_xbox[2 * (size_t)prim]; x1 = S.oct_xbox[2 * (size_t)prim + 1]; prim = __float_as_uint(x0.w); }
+                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                pin4(g0); pin4(g1); pin4(g2);
+                bool pass = true;
+                if (entering) {
+                    if (!explicit_box) {                               /* Triangle::world_bound (triangle.rs:152-158): the union of the three vertices */
+                        x0 = make_float4(fmin_(fmin_(g0.x, g1.x), g2.x), fmin_(fmin_(g0.y, g1.y), g2.y), fmin_(fmin_(g0.z, g1.z), g2.z), 0.0f);
+                        x1 = make_float4(fmax_(fmax_(g0.x, g1.x), g2.x), fmax_(fmax_(g0.y, g1.y), g2.y), fmax_(fmax_(g0.z, g1.z), g2.z), 0.0f);
+                    }
+                    pass = slab_test(x0, x1, R.o, R.inv, R.t_max);     /* the reference's test of the leaf node (bvh.rs:228) */
+                }
+                bool hh = false;
+                if (pass) {
+                    if (COUNT) n_prim++;
+                    float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                    hh = prim_hit<false>(S, prim, g0, g1, g2, R.o, R.dorig, R.t_max, R.kz, R.sx, R.sy, R.sz, &t, &b0, &b1, &b2);
+                }
+                if (hh) { found = true; L.finish = true; }
+                else if (!pass || (__float_as_uint(g0.w) & GF_LEAF_END)) {
+                    if (St.empty()) L.finish = true;
+                    else { const uint32_t next = St.template pop<true>(); if (next >> 31) { L.lp = next & 0x7fffffffu; L.mode = T8_LEAF; } else { L.cur = next; L.mode = T8_NODE; } }
+                } else { L.lp = prim + 1u; L.mode = T8_LEAF_IN; }
+            }
+        }
+        if (L.finish) { W.occluded[rid] = found ? 1 : 0; L.mode = T8_IDLE; }
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { n_rec += __shfl_down(n_rec, off, 64); n_prim += __shfl_down(n_prim, off, 64); }
+        if (lane == 0) {
+            if (n_rec) { atomicAdd(&stats->quad_records, n_rec); atomicAdd(&stats->quad_records_any, n_rec); }
+            if (n_prim) { atomicAdd(&stats->prims_tested, n_prim); atomicAdd(&stats->prims_any, n_prim); }
+            for (int k = 0; k < 7; k++) if (occ[k]) atomicAdd(&stats->t4_occ[7 + k], occ[k]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
+}
+
 /* ------------------------------------------------------------------ launch
  * LDS per workgroup decides the occupancy: the closest-hit kernel keeps `lds_entries` 8-byte levels per lane in LDS (2 KB per level
  * and workgroup), the any-hit kernel 4-byte levels; deeper levels live in `spill` (per lane, level-major). */
-Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_entries_dual) {
+Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_entries_dual, uint32_t knob_wg_oct) {
     Trace4Plan p; memset(&p, 0, sizeof(p));
     const uint32_t bound = S.quad_stack_bound ? S.quad_stack_bound : 1u;
     /* workgroups per CU the LDS stacks should leave room for.  Closest-hit: what its registers allow (96 VGPRs -> 5 waves per SIMD -> 5
@@ -581,6 +756,16 @@ Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest,
     p.spill_dual = ed_need - p.entries_dual;
     p.lds_dual = (size_t)p.entries_dual * 2u * 256u * 4u;
     p.grid_dual = (unsigned)n_cu * per_cu(p.lds_dual, wg_a);
+    /* eight-box occlusion records (k_wf_trace8_any): 4-byte entries, their own stack bound */
+    if (S.oct && S.n_octs) {
+        const uint32_t wg_8 = knob_wg_oct ? knob_wg_oct : 4u, budget_8 = ((158u * 1024u) / wg_8) & ~1023u, bound8 = S.oct_stack_bound ? S.oct_stack_bound : 1u;
+        const uint32_t e8 = budget_8 / (256u * 4u);
+        p.entries_oct = e8 < bound8 ? e8 : bound8;
+        p.spill_oct = bound8 - p.entries_oct;
+        p.lds_oct = (size_t)p.entries_oct * 256u * 4u;
+        p.grid_oct = (unsigned)n_cu * per_cu(p.lds_oct, wg_8);
+        p.oct_ok = true;
+    }
     return p;
 }
 
@@ -588,7 +773,12 @@ void launch_trace4(int kind, bool count, bool spheres, unsigned grid, size_t lds
                    const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t burst, uint32_t any_policy, uint32_t spill_levels) {
     const bool any = kind != T4K_CLOSEST;
 #define FTN_T4(K, SPILL_T, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), dim3(grid), dim3(256), lds, stream, S, W, queue, count_ptr, head, stats, refill, leaf_batch, chunk, lds_entries, (SPILL_T)spill, spill_levels)
-    if (kind == T4K_ANY_DUAL) {       /* (triangle-only scenes: the caller checked) */
+    if (kind == T4K_ANY_OCT) {        /* (triangle-only scenes with eight-box records: the caller checked) */
+#define FTN_T8(C, B) do { if (any_policy == 0) FTN_T4(k_wf_trace8_any, uint32_t*, C, B, 0); else FTN_T4(k_wf_trace8_any, uint32_t*, C, B, 1); } while (0)
+        if (count) FTN_T8(true, 2);
+        else if (burst <= 1) FTN_T8(false, 1); else if (burst == 2) FTN_T8(false, 2); else FTN_T8(false, 3);
+#undef FTN_T8
+    } else if (kind == T4K_ANY_DUAL) {       /* (triangle-only scenes: the caller checked) */
 #define FTN_T4D(C, B) do { if (any_policy == 0) FTN_T4(k_wf_trace4_any_dual, uint32_t*, C, B, 0); else FTN_T4(k_wf_trace4_any_dual, uint32_t*, C, B, 1); } while (0)
         if (count) FTN_T4D(true, 2);
         else if (burst <= 1) FTN_T4D(false, 1); else if (burst == 2) FTN_T4D(false, 2); else if (burst == 3) FTN_T4D(false, 3); else FTN_T4D(false, 4);

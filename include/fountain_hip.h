@@ -355,6 +355,12 @@ int ftn_bvh_build(const ftn_scene_desc* desc, ftn_bvh_node* nodes_out, uint32_t*
  * records_out: capacity 32 * (number of interior nodes) floats, or NULL to query the counts. */
 int ftn_bvh_quads(const ftn_bvh_node* nodes, uint32_t n_nodes, float* records_out, uint32_t* n_records_out, uint32_t* stack_bound_out);
 
+/* The eight-box occlusion records the any-hit kernel walks in triangle-only scenes (fountain_amd/csrc/ftn_host.cpp build_octs: a second
+ * tree over the reference's leaves with outward-rounded 8-bit boxes; exact because intersect_test only depends on which LEAF boxes and
+ * primitives a ray passes).  Host-only, for tests: 32 words per record, 8 floats {min, first primitive, max, 0} per explicit leaf box. */
+int ftn_bvh_octs(const ftn_bvh_node* nodes, uint32_t n_nodes, uint32_t* records_out, uint32_t* n_records_out, uint32_t* stack_bound_out,
+                 float* xbox_out, uint32_t* n_xbox_out);
+
 /* Introspection for parity tests. */
 int ftn_scene_info(const ftn_scene* scene, uint32_t* n_nodes, uint32_t* n_prims, uint32_t* n_lights,
                    uint32_t* max_depth, float world_bound[6]);
@@ -365,6 +371,7 @@ int ftn_scene_get_nodes(const ftn_scene* scene, ftn_bvh_node* nodes_out, uint32_
 typedef struct ftn_scene_memory {
     uint64_t nodes;             /* LinearBVHNode records, 32 B each (reference-order kernels: counting builds, exception rays, megakernel) */
     uint64_t quad;              /* four-box records, 128 B each (production traversal) */
+    uint64_t oct;               /* eight-box occlusion records, 128 B each + explicit leaf boxes (any-hit traversal of triangle scenes) */
     uint64_t fat;               /* two-box records, 64 B each (legacy any-hit kernel; 0 unless asked for) */
     uint64_t geom;              /* triangle vertices, 48 B per primitive (leaf tests) */
     uint64_t srec;              /* shading records, 128 B per primitive */

@@ -43,7 +43,7 @@ def test_version_and_error_strings(ftn):
 def test_oracle_exports_twins(orc):
     for name in header_functions():
         twin = "orc_" + name[4:]
-        if name in ("ftn_render_device", "ftn_device_count", "ftn_version", "ftn_abi_version", "ftn_scene_memory_info", "ftn_bvh_build", "ftn_bvh_quads", "ftn_test_math"):
+        if name in ("ftn_render_device", "ftn_device_count", "ftn_version", "ftn_abi_version", "ftn_scene_memory_info", "ftn_bvh_build", "ftn_bvh_quads", "ftn_bvh_octs", "ftn_test_math"):
             continue   # device-only / covered by orc_scene_get_nodes
         if name.startswith(("ftn_pbrt_", "ftn_ply_", "ftn_exr_", "ftn_imageio_")) or name in ("ftn_film_resolve_device", "ftn_test_mipmap_level", "ftn_test_texture_eval"):
             continue   # host-side file ingestion: checked against SceneBuilder in tests/test_pbrt_loader.py
