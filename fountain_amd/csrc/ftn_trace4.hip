@@ -388,170 +388,6 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
 }
 
-/* ------------------------------------------------------------------ any hit, two rays per lane (k_wf_trace4_any_dual)
- * The any-hit kernel above is bound by VALU issue with ~38 of 64 lanes live in a record step and ~21 in a leaf step: a lane is idle
- * whenever ITS ray is in the other mode (holds a leaf during record steps, walks records during a leaf step, waits for a refill).
- * Here every lane owns two rays: the slot in front (P) is the one the step bodies work on, the other one (Q) is parked in registers.
- * Before a phase a lane whose P is not in the phase's mode while its Q is swaps the two (14 registers, v_swap_b32), so a lane is
- * idle only when NEITHER of its rays is in the phase's mode.  Order is free for a boolean, so nothing else changes: same records,
- * same triangle tests per ray, same result bits.  Triangle-only scenes (sphere scenes keep the one-ray kernel: three more registers
- * per slot).
- * Slot state: cur / lp share one word (`pos`: a lane is at a record OR holds a leaf); mode, kz and the slot's stack region live in `fl`.
- * Stacks: LDS [level][lane], 4-byte entries, two regions of `lds_entries` levels per lane (byte offset of region r: r * lds_entries * 1024);
- * the bottom entry of a ray's stack is T4_NONE (popping it ends the ray), deeper levels than the region go to the global spill area. */
-struct T4Slot { float ox, oy, oz, ix, iy, iz, t_max, sx, sy, sz; uint32_t pos, fl, rid, sp; };      /* (plain words: every one of them stays in a register) */
-enum : uint32_t { T4S_MODE = 3u, T4S_KZ_SHIFT = 2u, T4S_REGION = 0xfffffc00u };
-struct T4DualStack { uint32_t lim0; uint32_t* spill; size_t n_lanes, gl; uint32_t spill_levels; };
-__device__ __forceinline__ uint32_t t4s_mode(const T4Slot& P) { return P.fl & T4S_MODE; }
-__device__ __forceinline__ void t4s_set_mode(T4Slot& P, uint32_t m) { P.fl = (P.fl & ~T4S_MODE) | m; }
-/* (v_swap_b32 under the branch's exec mask: one instruction per register instead of three moves through a temporary) */
-#define T4S_SWAP1(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-#define T4S_SWAP(A, B) do { T4S_SWAP1(A.ox, B.ox); T4S_SWAP1(A.oy, B.oy); T4S_SWAP1(A.oz, B.oz); T4S_SWAP1(A.ix, B.ix); T4S_SWAP1(A.iy, B.iy); T4S_SWAP1(A.iz, B.iz); \
-                            T4S_SWAP1(A.t_max, B.t_max); T4S_SWAP1(A.sx, B.sx); T4S_SWAP1(A.sy, B.sy); T4S_SWAP1(A.sz, B.sz); \
-                            T4S_SWAP1(A.pos, B.pos); T4S_SWAP1(A.fl, B.fl); T4S_SWAP1(A.rid, B.rid); T4S_SWAP1(A.sp, B.sp); } while (0)
-__device__ __forceinline__ uint32_t* t4d_lds(uint32_t off) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_stack1) + off); }
-/* one past the LDS levels of P's region */
-__device__ __forceinline__ uint32_t t4d_lim(const T4DualStack& D, const T4Slot& P) { return D.lim0 + (P.fl & T4S_REGION); }
-__device__ __forceinline__ size_t t4d_spill_at(const T4DualStack& D, const T4Slot& P) {
-    const uint32_t lv = (P.sp - t4d_lim(D, P)) >> 10, region = (P.fl & T4S_REGION) ? 1u : 0u;
-    return ((size_t)region * D.spill_levels + (lv < D.spill_levels ? lv : D.spill_levels - 1u)) * D.n_lanes + D.gl;
-}
-template <bool CHECK> __device__ __forceinline__ void t4d_push(const T4DualStack& D, T4Slot& P, uint32_t v) {
-    if (!CHECK || P.sp < t4d_lim(D, P)) *t4d_lds(P.sp) = v; else if (D.spill_levels) D.spill[t4d_spill_at(D, P)] = v;
-    P.sp += 1024u;
-}
-template <bool CHECK> __device__ __forceinline__ uint32_t t4d_pop(const T4DualStack& D, T4Slot& P) {
-    P.sp -= 1024u;
-    if (!CHECK || P.sp < t4d_lim(D, P)) return *t4d_lds(P.sp);
-    return D.spill_levels ? D.spill[t4d_spill_at(D, P)] : T4_NONE;
-}
-
-/* (the ray's seven floats come by value: read through the slot reference, the loads that feed the packed operations get widened into
- * overlapping two-float loads before this body is inlined, and the slot then stays in scratch memory in the kernel) */
-template <bool CHECK, int POLICY>
-__device__ __forceinline__ void t4d_any_step(const DScene& S, const T4DualStack& D, T4Slot& P, V3 o, V3 inv, float t_max, bool& finish) {
-    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.quad) + P.pos);
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
-    float a0, a1, b0, b1, c0, c1, d0, d1;
-    const bool ha = slab4(q0, q1, o, inv, t_max, &a0, &a1), hb = slab4(q2, q3, o, inv, t_max, &b0, &b1);
-    const bool hc = slab4(q4, q5, o, inv, t_max, &c0, &c1), hd = slab4(q6, q7, o, inv, t_max, &d0, &d1);
-    const uint32_t ea = __float_as_uint(q1.z), eb = __float_as_uint(q3.z), ec = __float_as_uint(q5.z), ed = __float_as_uint(q7.z);
-    uint32_t next = 0; const bool have = ha || hb || hc || hd;
-    if (POLICY == 1) {
-        const float sa = ha ? fmaxf(a1 - a0, 0.0f) : -1.0f, sb = hb ? fmaxf(b1 - b0, 0.0f) : -1.0f, sc = hc ? fmaxf(c1 - c0, 0.0f) : -1.0f, sd = hd ? fmaxf(d1 - d0, 0.0f) : -1.0f;
-        const float best = fmaxf(fmaxf(sa, sb), fmaxf(sc, sd));
-        const bool pa = sa == best, pb = !pa && sb == best, pc = !pa && !pb && sc == best, pd = !pa && !pb && !pc;
-        next = pa ? ea : (pb ? eb : (pc ? ec : ed));
-        if (ha && !pa) t4d_push<CHECK>(D, P, ea);
-        if (hb && !pb) t4d_push<CHECK>(D, P, eb);
-        if (hc && !pc) t4d_push<CHECK>(D, P, ec);
-        if (hd && !pd) t4d_push<CHECK>(D, P, ed);
-    } else {
-        next = ha ? ea : (hb ? eb : (hc ? ec : ed));
-        if (hd && (ha || hb || hc)) t4d_push<CHECK>(D, P, ed);
-        if (hc && (ha || hb)) t4d_push<CHECK>(D, P, ec);
-        if (hb && ha) t4d_push<CHECK>(D, P, eb);
-    }
-    if (!have) next = t4d_pop<CHECK>(D, P);
-    /* (an empty slot's link is T4_NONE too; ray_is_exceptional keeps the rays away that could enter one) */
-    if (next == T4_NONE) { finish = true; return; }
-    if (next >> 31) { P.pos = next & 0x7fffffffu; t4s_set_mode(P, T4_LEAF); } else P.pos = next;
-}
-
-template <bool COUNT, int BURST, int POLICY>
-__global__ void __launch_bounds__(256) k_wf_trace4_any_dual(DScene S, WfBuffers W, const uint32_t* __restrict__ queue, const uint32_t* count_ptr, uint32_t* head, DevStats* stats,
-                                                            uint32_t refill, uint32_t leaf_batch, uint32_t chunk_max, uint32_t lds_entries, uint32_t* __restrict__ spill, uint32_t spill_levels) {
-    const uint32_t region = lds_entries * 1024u;
-    T4DualStack D; D.lim0 = threadIdx.x * 4u + region; D.spill = spill; D.spill_levels = spill_levels;
-    D.n_lanes = (size_t)gridDim.x * 256u; D.gl = (size_t)blockIdx.x * 256u + threadIdx.x;
-    const uint32_t soft0 = D.lim0 - 3u * 1024u;                    /* (the host gives a region at least four levels) */
-    const uint32_t count = *count_ptr;
-    const uint32_t lane = lane_id();
-    unsigned long long n_rec = 0, n_prim = 0;
-    unsigned long long occ[7] = {0, 0, 0, 0, 0, 0, 0};
-    T4Slot P, Q;
-    P.ox = P.oy = P.oz = P.ix = P.iy = P.iz = P.t_max = P.sx = P.sy = P.sz = 0.0f; P.pos = 0; P.rid = 0; P.sp = threadIdx.x * 4u; P.fl = T4_IDLE;
-    Q.ox = Q.oy = Q.oz = Q.ix = Q.iy = Q.iz = Q.t_max = Q.sx = Q.sy = Q.sz = 0.0f; Q.pos = 0; Q.rid = 0; Q.sp = P.sp + region; Q.fl = T4_IDLE | region;
-    WaveQueue Wq; wq_init(Wq, count, chunk_max);
-    const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f), rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
-    for (;;) {
-        /* ---- re-arm: every lane with an idle slot takes one ray (a lane with two idle slots takes its second one next time round) */
-        const unsigned long long want = __ballot(t4s_mode(P) == T4_IDLE || t4s_mode(Q) == T4_IDLE);
-        if (!Wq.exhausted && (uint32_t)__popcll(want) >= refill) {
-            if (t4s_mode(P) != T4_IDLE && t4s_mode(Q) == T4_IDLE) T4S_SWAP(P, Q);        /* the idle slot to the front */
-            const uint32_t need = (uint32_t)__popcll(want);
-            (void)wq_refill(Wq, count, head, lane);
-            const uint32_t avail = Wq.chunk_end - Wq.chunk_next;
-            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-            bool hand_back = false; uint32_t q_entry = 0;
-            if (COUNT) { occ[5]++; occ[6] += need < avail ? need : avail; }
-            if (t4s_mode(P) == T4_IDLE && rank < avail) {
-                float4 a, b; RaySetup R;
-                q_entry = queue[Wq.chunk_next + rank];
-                uint32_t slot = 0;
-                load_queued_ray<true>(W, q_entry, &a, &b, &slot);
-                P.rid = slot;
-                ray_setup<false>(R, a, b);
-                P.ox = R.o.x; P.oy = R.o.y; P.oz = R.o.z; P.ix = R.inv.x; P.iy = R.inv.y; P.iz = R.inv.z; P.t_max = R.t_max; P.sx = R.sx; P.sy = R.sy; P.sz = R.sz; P.pos = 0;
-                P.fl = (P.fl & T4S_REGION) | ((uint32_t)R.kz << T4S_KZ_SHIFT);                                /* idle */
-                P.sp = threadIdx.x * 4u + (P.fl & T4S_REGION);
-                *t4d_lds(P.sp) = T4_NONE; P.sp += 1024u;                                                       /* the stack's bottom */
-                if (ray_is_exceptional(R.o.x, R.o.y, R.o.z, R.inv.x, R.inv.y, R.inv.z)) hand_back = true;
-                else if (S.n_nodes == 0 || !slab_test(rlo, rhi, R.o, R.inv, R.t_max)) W.occluded[P.rid] = 0;
-                else if (S.root_is_leaf) P.fl |= T4_LEAF;
-                else P.fl |= T4_NODE;
-            }
-            if (__ballot(hand_back) != 0) wave_push(hand_back, q_entry, W.q_exc_any, &W.counters[CTR(33)]);
-            Wq.chunk_next += (need < avail ? need : avail);
-        }
-        const unsigned long long m_node = __ballot(t4s_mode(P) == T4_NODE || t4s_mode(Q) == T4_NODE), m_leaf = __ballot(t4s_mode(P) == T4_LEAF || t4s_mode(Q) == T4_LEAF);
-        if ((m_node | m_leaf) == 0) { if (Wq.exhausted) break; else continue; }
-        bool finish = false, found = false;
-        if (COUNT) occ[0]++;
-        if (m_node != 0 && (uint32_t)__popcll(m_leaf) < leaf_batch) {
-            /* ---- record steps */
-            if (t4s_mode(P) != T4_NODE && t4s_mode(Q) == T4_NODE) T4S_SWAP(P, Q);
-#pragma unroll
-            for (int burst = 0; burst < BURST; burst++) {
-                const bool on = t4s_mode(P) == T4_NODE && !finish;
-                if (COUNT && on) n_rec++;
-                if (COUNT) { const unsigned long long m_on = __ballot(on); if (m_on) { occ[1]++; occ[2] += (unsigned long long)__popcll(m_on); } }
-                if (__builtin_expect(__ballot(on && P.sp > soft0 + (P.fl & T4S_REGION)) == 0, 1)) { if (on) t4d_any_step<false, POLICY>(S, D, P, V3(P.ox, P.oy, P.oz), V3(P.ix, P.iy, P.iz), P.t_max, finish); }
-                else if (on) t4d_any_step<true, POLICY>(S, D, P, V3(P.ox, P.oy, P.oz), V3(P.ix, P.iy, P.iz), P.t_max, finish);
-            }
-        } else {
-            /* ---- leaf step: one primitive per lane */
-            if (t4s_mode(P) != T4_LEAF && t4s_mode(Q) == T4_LEAF) T4S_SWAP(P, Q);
-            if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(__ballot(t4s_mode(P) == T4_LEAF)); }
-            if (t4s_mode(P) == T4_LEAF) {
-                const uint32_t prim = P.pos;
-                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
-                pin4(g0); pin4(g1); pin4(g2);
-                if (COUNT) n_prim++;
-                float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-                const bool hh = prim_hit<false>(S, prim, g0, g1, g2, V3(P.ox, P.oy, P.oz), V3(0.0f, 0.0f, 0.0f), P.t_max, (int)((P.fl >> T4S_KZ_SHIFT) & 3u), P.sx, P.sy, P.sz, &t, &b0, &b1, &b2);
-                if (hh) { found = true; finish = true; }
-                else if (__float_as_uint(g0.w) & GF_LEAF_END) {
-                    const uint32_t next = t4d_pop<true>(D, P);
-                    if (next == T4_NONE) finish = true;
-                    else if (next >> 31) P.pos = next & 0x7fffffffu;
-                    else { P.pos = next; t4s_set_mode(P, T4_NODE); }
-                } else P.pos++;
-            }
-        }
-        if (finish) { W.occluded[P.rid] = found ? 1 : 0; t4s_set_mode(P, T4_IDLE); }
-    }
-    if (COUNT) {
-        for (int off = 32; off > 0; off >>= 1) { n_rec += __shfl_down(n_rec, off, 64); n_prim += __shfl_down(n_prim, off, 64); }
-        if (lane == 0) {
-            if (n_rec) { atomicAdd(&stats->quad_records, n_rec); atomicAdd(&stats->quad_records_any, n_rec); }
-            if (n_prim) { atomicAdd(&stats->prims_tested, n_prim); atomicAdd(&stats->prims_any, n_prim); }
-            for (int k = 0; k < 7; k++) if (occ[k]) atomicAdd(&stats->t4_occ[7 + k], occ[k]);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->rays_any, (unsigned long long)count);
-}
-
 /* ------------------------------------------------------------------ any hit over eight-box occlusion records (k_wf_trace8_any; DScene::oct, build_octs in ftn_host.cpp)
  * intersect_test returns a boolean and never shrinks t_max: a ray is occluded iff some LEAF's own box passes the slab test and one of the
  * leaf's primitives passes its test -- the interior boxes on the way only have to let every such leaf be reached, so they may be larger
@@ -730,7 +566,7 @@ __global__ void __launch_bounds__(256) k_wf_trace8_any(DScene S, WfBuffers W, co
 /* ------------------------------------------------------------------ launch
  * LDS per workgroup decides the occupancy: the closest-hit kernel keeps `lds_entries` 8-byte levels per lane in LDS (2 KB per level
  * and workgroup), the any-hit kernel 4-byte levels; deeper levels live in `spill` (per lane, level-major). */
-Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_entries_dual, uint32_t knob_wg_oct) {
+Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_wg_oct) {
     Trace4Plan p; memset(&p, 0, sizeof(p));
     const uint32_t bound = S.quad_stack_bound ? S.quad_stack_bound : 1u;
     /* workgroups per CU the LDS stacks should leave room for.  Closest-hit: what its registers allow (96 VGPRs -> 5 waves per SIMD -> 5
@@ -748,17 +584,9 @@ Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest,
     p.lds_closest = (size_t)p.entries_closest * 256u * 8u; p.lds_any = (size_t)p.entries_any * 256u * 4u;
     auto per_cu = [](size_t lds, uint32_t wg) { return (unsigned)std::max<size_t>(1, std::min<size_t>(wg, (size_t)(158 * 1024) / std::max<size_t>(lds, 1))); };
     p.grid_closest = (unsigned)n_cu * per_cu(p.lds_closest, wg_c); p.grid_any = (unsigned)n_cu * per_cu(p.lds_any, wg_a);
-    /* two rays per lane (k_wf_trace4_any_dual): two stack regions per lane out of the same LDS budget, one level more per ray for the
-     * bottom marker; a budget that leaves a region fewer than four levels keeps the one-ray kernel */
-    const uint32_t ed_budget = knob_entries_dual ? knob_entries_dual : budget_a / (256u * 4u) / 2u, ed_need = bound + 1u;
-    p.entries_dual = ed_budget < ed_need ? ed_budget : ed_need;
-    p.dual_ok = p.entries_dual >= 4u;
-    p.spill_dual = ed_need - p.entries_dual;
-    p.lds_dual = (size_t)p.entries_dual * 2u * 256u * 4u;
-    p.grid_dual = (unsigned)n_cu * per_cu(p.lds_dual, wg_a);
     /* eight-box occlusion records (k_wf_trace8_any): 4-byte entries, their own stack bound */
     if (S.oct && S.n_octs) {
-        const uint32_t wg_8 = knob_wg_oct ? knob_wg_oct : 4u, budget_8 = ((158u * 1024u) / wg_8) & ~1023u, bound8 = S.oct_stack_bound ? S.oct_stack_bound : 1u;
+        const uint32_t wg_8 = knob_wg_oct ? knob_wg_oct : 5u, budget_8 = ((158u * 1024u) / wg_8) & ~1023u, bound8 = S.oct_stack_bound ? S.oct_stack_bound : 1u;
         const uint32_t e8 = budget_8 / (256u * 4u);
         p.entries_oct = e8 < bound8 ? e8 : bound8;
         p.spill_oct = bound8 - p.entries_oct;
@@ -778,11 +606,6 @@ void launch_trace4(int kind, bool count, bool spheres, unsigned grid, size_t lds
         if (count) FTN_T8(true, 2);
         else if (burst <= 1) FTN_T8(false, 1); else if (burst == 2) FTN_T8(false, 2); else FTN_T8(false, 3);
 #undef FTN_T8
-    } else if (kind == T4K_ANY_DUAL) {       /* (triangle-only scenes: the caller checked) */
-#define FTN_T4D(C, B) do { if (any_policy == 0) FTN_T4(k_wf_trace4_any_dual, uint32_t*, C, B, 0); else FTN_T4(k_wf_trace4_any_dual, uint32_t*, C, B, 1); } while (0)
-        if (count) FTN_T4D(true, 2);
-        else if (burst <= 1) FTN_T4D(false, 1); else if (burst == 2) FTN_T4D(false, 2); else if (burst == 3) FTN_T4D(false, 3); else FTN_T4D(false, 4);
-#undef FTN_T4D
     } else if (any) {
 #define FTN_T4A(C, Sp, B) do { if (any_policy == 0) FTN_T4(k_wf_trace4_any, uint32_t*, C, Sp, B, 0); else FTN_T4(k_wf_trace4_any, uint32_t*, C, Sp, B, 1); } while (0)
         if (count) { if (spheres) FTN_T4A(true, true, 2); else FTN_T4A(true, false, 2); }

@@ -1104,7 +1104,7 @@ struct WavefrontState {
     /* four-box traversal (ftn_trace4.hip): launch plan of the current call and the global spill areas behind the LDS stacks */
     /* buffers of the direct-lighting / Whitted mode (grow-only): level terms, and shadow-ray records / results / queue sized for one ray per light */
     void* dl_mem[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t dl_paths = 0; uint32_t dl_levels = 0, dl_slots = 0; bool dl_tex = false;
-    Trace4Plan t4; bool t4_on = false, t4_dual = false, t8_on = false;
+    Trace4Plan t4; bool t4_on = false, t8_on = false;
     void* ser_mem[4] = {nullptr, nullptr, nullptr, nullptr}; size_t ser_paths = 0; bool ser_tex = false; uint32_t* ser_host = nullptr;      /* tile-serial sampler on the queues: cursor, film position, retired flag, differentials */
     void* t4_spill_c = nullptr; void* t4_spill_a = nullptr; size_t t4_spill_c_bytes = 0, t4_spill_a_bytes = 0;
 };
@@ -1184,14 +1184,12 @@ static uint32_t g_probe_bounce = 0;
 static int trace4_prepare(WavefrontState* st, const DScene& S) {
     st->t4_on = S.quad != nullptr && knob("FTN_TRACE4", 1) != 0;
     if (!st->t4_on) return FTN_OK;
-    st->t4 = trace4_plan(S, st->n_cu, knob("FTN_T4_ENTRIES", 0), knob("FTN_T4_ENTRIES_ANY", 0), knob("FTN_T4_WG", 0), knob("FTN_T4_WG_ANY", 0), knob("FTN_T4_ENTRIES_DUAL", 0), knob("FTN_T8_WG", 0));
-    /* two rays per lane in the any-hit kernel: triangle-only scenes (FTN_T4_ANY_DUAL=0: the one-ray kernel) */
-    st->t4_dual = st->t4.dual_ok && S.n_spheres == 0 && knob("FTN_T4_ANY_DUAL", 1) != 0;
+    st->t4 = trace4_plan(S, st->n_cu, knob("FTN_T4_ENTRIES", 0), knob("FTN_T4_ENTRIES_ANY", 0), knob("FTN_T4_WG", 0), knob("FTN_T4_WG_ANY", 0), knob("FTN_T8_WG", 0));
     const size_t need_c = (size_t)st->t4.grid_closest * 256u * st->t4.spill_closest * sizeof(uint2);
     /* eight-box occlusion records for the any-hit rays of triangle-only scenes (FTN_T8=0: the four-box kernels trace them) */
     st->t8_on = st->t4.oct_ok && S.n_spheres == 0 && knob("FTN_T8", 1) != 0;
     const size_t need_a8 = st->t8_on ? (size_t)st->t4.grid_oct * 256u * st->t4.spill_oct * sizeof(uint32_t) : 0;
-    const size_t need_a = std::max<size_t>(need_a8, st->t4_dual ? (size_t)st->t4.grid_dual * 256u * 2u * st->t4.spill_dual * sizeof(uint32_t) : (size_t)st->t4.grid_any * 256u * st->t4.spill_any * sizeof(uint32_t));
+    const size_t need_a = std::max<size_t>(need_a8, (size_t)st->t4.grid_any * 256u * st->t4.spill_any * sizeof(uint32_t));
     if (need_c > st->t4_spill_c_bytes) { if (st->t4_spill_c) (void)hipFree(st->t4_spill_c); st->t4_spill_c = nullptr; st->t4_spill_c_bytes = 0; WF_TRY(hipMalloc(&st->t4_spill_c, need_c)); st->t4_spill_c_bytes = need_c; }
     if (need_a > st->t4_spill_a_bytes) { if (st->t4_spill_a) (void)hipFree(st->t4_spill_a); st->t4_spill_a = nullptr; st->t4_spill_a_bytes = 0; WF_TRY(hipMalloc(&st->t4_spill_a, need_a)); st->t4_spill_a_bytes = need_a; }
     return FTN_OK;
@@ -1204,16 +1202,13 @@ static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, 
     if (st->t4_on && count != 1) {     /* four-box records */
         const Trace4Plan& T = st->t4;
         const bool oct = any && st->t8_on;
-        const bool dual = any && !oct && st->t4_dual;
-        const unsigned g = std::min<unsigned>(oct ? T.grid_oct : dual ? T.grid_dual : (any ? T.grid_any : T.grid_closest), std::max<unsigned>(1u, (max_rays + 255u) / 256u));
+        const unsigned g = std::min<unsigned>(oct ? T.grid_oct : (any ? T.grid_any : T.grid_closest), std::max<unsigned>(1u, (max_rays + 255u) / 256u));
         uint32_t chunk4 = knob("FTN_TRACE_CHUNK", 128);
         while (chunk4 > 64u && (uint64_t)chunk4 * g * 4u * 4u > (uint64_t)max_rays) chunk4 >>= 1;
-        /* measured optima on the config-5 scene (profiles/r02_*, r03): lanes re-armed once 24 (closest) / 32 (any-hit) are idle, leaf steps run
-         * once 16 lanes hold a leaf, 2 / 4 record steps per control round */
+        /* measured optima on the config-5 scene (profiles/r02_*, r03): lanes re-armed once 24 (closest, eight-box any-hit) / 32 (four-box any-hit)
+         * are idle, leaf steps run once 16 lanes hold a leaf, 2 / 4 record steps per control round */
         if (oct) launch_trace4(T4K_ANY_OCT, count == 2, false, g, T.lds_oct, T.entries_oct, st->t4_spill_a, stream, P.S, W, queue, count_ptr, head, P.stats,
-                               knob("FTN_T8_REFILL", 32), knob("FTN_T8_LEAF_BATCH", 16), chunk4, knob("FTN_T8_BURST", 2), knob("FTN_T8_POLICY", 1), T.spill_oct);
-        else if (dual) launch_trace4(T4K_ANY_DUAL, count == 2, false, g, T.lds_dual, T.entries_dual, st->t4_spill_a, stream, P.S, W, queue, count_ptr, head, P.stats,
-                                std::min<uint32_t>(std::max<uint32_t>(knob("FTN_T4_DUAL_REFILL", 48), 1u), 64u), knob("FTN_T4_DUAL_LEAF_BATCH", 24), chunk4, knob("FTN_T4_DUAL_BURST", 3), knob("FTN_T4_ANY_POLICY", 1), T.spill_dual);
+                               knob("FTN_T8_REFILL", 24), knob("FTN_T8_LEAF_BATCH", 16), chunk4, knob("FTN_T8_BURST", 2), knob("FTN_T8_POLICY", 1), T.spill_oct);
         else launch_trace4(any ? T4K_ANY : T4K_CLOSEST, count == 2, spheres, g, any ? T.lds_any : T.lds_closest, any ? T.entries_any : T.entries_closest, any ? st->t4_spill_a : st->t4_spill_c, stream, P.S, W,
                       queue, count_ptr, head, P.stats,
                       any ? knob("FTN_T4_ANY_REFILL", 32) : knob("FTN_T4_REFILL", 24), any ? knob("FTN_T4_ANY_LEAF_BATCH", 16) : knob("FTN_T4_LEAF_BATCH", 16), chunk4,

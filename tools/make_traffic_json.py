@@ -40,8 +40,8 @@ def source_hash():
 def group_of(name):
     """kernel name -> (group, counting build?)"""
     n = name
-    counting = ("k_wf_trace4<true" in n) or ("k_wf_trace4_any<true" in n) or ("k_wf_trace4_any_dual<true" in n) or ("k_wf_trace<false, true" in n) or ("k_wf_trace<true, true" in n)
-    if "k_wf_trace4_any" in n or "k_wf_trace_any2" in n or "k_wf_trace<true" in n:
+    counting = ("k_wf_trace4<true" in n) or ("k_wf_trace4_any<true" in n) or ("k_wf_trace8_any<true" in n) or ("k_wf_trace<false, true" in n) or ("k_wf_trace<true, true" in n)
+    if "k_wf_trace8_any" in n or "k_wf_trace4_any" in n or "k_wf_trace_any2" in n or "k_wf_trace<true" in n:
         return "any_hit", counting
     if "k_wf_trace4" in n or "k_wf_trace<false" in n:
         return "closest", counting
