@@ -29,11 +29,8 @@ namespace ftn {
 
 #define FTN_DEV_NOINLINE __device__ inline   /* out-of-line variants were measured slower (see detmath.h) */
 
-/* float4s per primitive in DScene::geom: 4 = one 64-byte half line per primitive (a 48-byte record at stride 48 straddles two 128-byte
- * lines one time in three, and a leaf test is a random fetch: 1.33 lines instead of 1) */
-#ifndef FTN_GS
+/* float4s per primitive in the HOST copy of the leaf-test records (the device stride is DScene::geom_stride) */
 #define FTN_GS 3
-#endif
 enum : uint32_t { GF_KIND_SPHERE = 1u, GF_HAS_NORMALS = 2u, GF_HAS_UVS = 4u, GF_FLIP = 8u, GF_LEAF_END = 16u /* last primitive of its BVH leaf */, GF_HAS_TANGENTS = 32u /* per-vertex shading tangents in DScene::T */ };
 enum : uint32_t { LK_POINT = 0, LK_DISTANT = 1, LK_INFINITE = 2, LK_AREA = 3 };
 
@@ -69,6 +66,10 @@ struct DImage { uint32_t w, h, wrap, n_levels; uint32_t off[16], lw[16], lh[16];
 
 struct DScene {
     const float4* nodes; const float4* geom; const uint4* prim_info;
+    /* float4s between two primitives' leaf-test records {p0, flags} {p1, shape index} {p2, -}: 3 = the dense `geom` array; 8 = `geom` is the
+     * shading-record array itself (its first 48 bytes are the same three vertices): triangle-only scenes with shading records keep no
+     * separate copy -- a leaf test is a random 128-byte line either way (measured: no difference, profiles/r03) and 480 MB stay free */
+    uint32_t geom_stride, _pad_gs;
     const float* N; const float* UV;
     const float* T;                         /* per-vertex shading tangents ("S", triangle.rs:341-347) or NULL; gathered through prim_info's vertex indices */
     const DSphere* spheres; const ftn_material* materials; const DLight* lights;
@@ -347,7 +348,7 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
                 const uint32_t n = meta & 0xffffu;
                 for (uint32_t i = 0; i < n; i++) {
                     const uint32_t prim = idx + i;
-                    float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                    float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
                     pin4(g0); pin4(g1); pin4(g2);
                     if (COUNT) tc->prims++;
                     const uint32_t fl = __float_as_uint(g0.w);
@@ -380,7 +381,7 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
 
 /* ------------------------------------------------------------------ shading geometry from a compact hit */
 __device__ inline void load_tri(const DScene& S, int prim, V3* p0, V3* p1, V3* p2, uint32_t* flags) {
-    const float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+    const float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
     *p0 = V3(g0.x, g0.y, g0.z); *p1 = V3(g1.x, g1.y, g1.z); *p2 = V3(g2.x, g2.y, g2.z); *flags = __float_as_uint(g0.w);
 }
 /* triangle.rs:270-393 */
@@ -482,10 +483,10 @@ FTN_DEV_NOINLINE void tri_interaction(const DScene& S, const DHit& h, V3 ray_d, 
     si->hit.n = n; si->shading_n = sn; si->prim = h.prim;
 }
 __device__ inline bool make_interaction(const DScene& S, const DHit& h, const DRay& ray_before_hit, DSI* si, DSIX* ex = nullptr) {
-    const float4 g0 = S.srec ? S.srec[8 * (size_t)h.prim] : S.geom[FTN_GS * h.prim];
+    const float4 g0 = S.srec ? S.srec[8 * (size_t)h.prim] : S.geom[S.geom_stride * h.prim];
     if (__float_as_uint(g0.w) & GF_KIND_SPHERE) {
         DRay r = ray_before_hit; r.t_max = FTN_INF;   /* same root selection as at traversal time */
-        float t; const float4 g1 = S.geom[FTN_GS * h.prim + 1];
+        float t; const float4 g1 = S.geom[S.geom_stride * h.prim + 1];
         bool ok = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, si, ex);
         si->prim = h.prim; prim_mat_light(S, h.prim, &si->mat, &si->light);
         return ok;
@@ -496,7 +497,7 @@ __device__ inline bool make_interaction(const DScene& S, const DHit& h, const DR
 
 /* ------------------------------------------------------------------ shapes as emitters: shapes/mod.rs:39-66 */
 FTN_DEV_NOINLINE DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
-    const float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+    const float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
     const uint32_t fl = __float_as_uint(g0.w);
     DSurfHit h;
     if (fl & GF_KIND_SPHERE) {                                   /* sphere.rs:202-218 */
@@ -529,10 +530,10 @@ FTN_DEV_NOINLINE DSurfHit shape_sample(const DScene& S, int prim, V2 u) {
 /* Shape::pdf_from_ref: intersects the light's own shape, bypassing the BVH (shapes/mod.rs:55-66) */
 FTN_DEV_NOINLINE float shape_pdf_from_ref(const DScene& S, int prim, float area, const DSurfHit& ref, V3 wi) {
     DRay ray = spawn_ray(ref, wi);
-    const float4 g0 = S.geom[FTN_GS * prim];
+    const float4 g0 = S.geom[S.geom_stride * prim];
     V3 hp, hn;
     if (__float_as_uint(g0.w) & GF_KIND_SPHERE) {
-        DSI si; float t; const float4 g1 = S.geom[FTN_GS * prim + 1];
+        DSI si; float t; const float4 g1 = S.geom[S.geom_stride * prim + 1];
         if (!sphere_intersect(S.spheres[__float_as_uint(g1.w)], ray, &t, &si)) return 0.0f;
         hp = si.hit.p; hn = si.hit.n;
     } else {

@@ -817,7 +817,6 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     }
     int rc;
     if ((rc = sc->nodes.upload(nodes.data(), nodes.size()))) return rc;
-    if ((rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
     /* two-box record links are 31-bit byte offsets: beyond 2^25 interior nodes the any-hit kernel falls back to the plain node walk */
     if (n_fat && n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
     /* four-box records (DScene::quad): what the production traversal kernels walk.  FTN_QUAD=0: not built (the two-record kernels run) */
@@ -868,6 +867,9 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if ((rc = sc->srec.upload(rec.data(), rec.size()))) return rc;
         }
     }
+    /* leaf-test records: the shading records' first 48 bytes in triangle-only scenes (DScene::geom_stride = 8), the dense array otherwise */
+    const bool geom_in_srec = sc->srec.p != nullptr && d->n_spheres == 0 && !env_is("FTN_GEOM", 1);
+    if (!geom_in_srec && (rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
     /* prim_info and the per-vertex normals / uvs: what the shading records replace (ftn_device.h: prim_mat_light / prim_normals / prim_uvs).
      * Resident only without records, or when a mesh has shading tangents (gathered through prim_info's vertex indices) */
     bool any_tangents = false;
@@ -981,7 +983,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     if ((rc = sc->lights.upload(lights.data(), lights.size()))) return rc;
     if ((rc = sc->inf_lights.upload(inf.data(), inf.size()))) return rc;
     DScene& D = sc->d; memset(&D, 0, sizeof(D));
-    D.nodes = sc->nodes.p; D.geom = sc->geom.p; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.T = sc->T.p; D.spheres = sc->spheres.p;
+    D.nodes = sc->nodes.p; D.geom = geom_in_srec ? sc->srec.p : sc->geom.p; D.geom_stride = geom_in_srec ? 8u : (uint32_t)FTN_GS; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.T = sc->T.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
     D.n_nodes = (uint32_t)hs.nodes.size(); D.n_prims = (uint32_t)np; D.n_lights = (uint32_t)lights.size(); D.n_inf_lights = (uint32_t)inf.size(); D.n_spheres = d->n_spheres;
     D.srec = sc->srec.p; D.prim_class = sc->prim_class.p;

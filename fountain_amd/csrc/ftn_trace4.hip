@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256, (SPHERES ? 1 : 5)) k_wf_trace4(DScene S, 
             if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
             if (L.mode == T4_LEAF) {
                 const uint32_t prim = L.lp;
-                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) n_prim++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
             if (COUNT) { occ[3]++; occ[4] += (unsigned long long)__popcll(m_leaf); }
             if (L.mode == T4_LEAF) {
                 const uint32_t prim = L.lp;
-                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) n_prim++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(256) k_wf_trace8_any(DScene S, WfBuffers W, co
                 float4 x0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), x1 = x0;
                 const bool explicit_box = entering && (L.lp & T8_XBOX);
                 if (explicit_box) { x0 = S.oct_xbox[2 * (size_t)prim]; x1 = S.oct_xbox[2 * (size_t)prim + 1]; prim = __float_as_uint(x0.w); }
-                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 bool pass = true;
                 if (entering) {

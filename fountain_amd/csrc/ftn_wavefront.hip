@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             if (COUNT) w_leaf_steps++;
             if (mode == TM_LEAF) {
                 const uint32_t prim = lp;
-                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 if (COUNT) tc.prims++;
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
         } else {
             if (mode == TM_LEAF) {
                 const uint32_t prim = lp;
-                float4 g0 = S.geom[FTN_GS * prim], g1 = S.geom[FTN_GS * prim + 1], g2 = S.geom[FTN_GS * prim + 2];
+                float4 g0 = S.geom[S.geom_stride * prim], g1 = S.geom[S.geom_stride * prim + 1], g2 = S.geom[S.geom_stride * prim + 2];
                 pin4(g0); pin4(g1); pin4(g2);
                 float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 const bool hh = prim_hit<SPHERES>(S, prim, g0, g1, g2, o, dorig, t_max, kz, sx, sy, sz, &t, &b0, &b1, &b2);
