@@ -421,12 +421,14 @@ __device__ inline T8Axis t8_axis(float org, uint32_t ebyte, float o, float inv, 
     return A;
 }
 #define T8_BYTE(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
-/* child c of the record: conservative entry / exit distances */
+/* child c of the record: conservative entry / exit distances.  The near and the far plane of an axis share the slope `a`: one packed
+ * fused multiply-add (v_pk_fma_f32: each half is the scalar fma) gives both */
 #define T8_CHILD(c, t0v, t1v) \
     { const uint32_t kx_ = (c) & 3; \
-      const float nx_ = fmaf(T8_BYTE((c) < 4 ? X.n03 : X.n47, kx_), X.a, X.bn), ny_ = fmaf(T8_BYTE((c) < 4 ? Y.n03 : Y.n47, kx_), Y.a, Y.bn), nz_ = fmaf(T8_BYTE((c) < 4 ? Z.n03 : Z.n47, kx_), Z.a, Z.bn); \
-      const float fx_ = fmaf(T8_BYTE((c) < 4 ? X.f03 : X.f47, kx_), X.a, X.bf), fy_ = fmaf(T8_BYTE((c) < 4 ? Y.f03 : Y.f47, kx_), Y.a, Y.bf), fz_ = fmaf(T8_BYTE((c) < 4 ? Z.f03 : Z.f47, kx_), Z.a, Z.bf); \
-      t0v = fmax_(fmax_(fmax_(0.0f, nx_), ny_), nz_); t1v = fmin_(t_max, fmin_(fmin_(fx_, fy_), fz_) * k2); }
+      const t4_f2 tx_ = __builtin_elementwise_fma((t4_f2){T8_BYTE((c) < 4 ? X.n03 : X.n47, kx_), T8_BYTE((c) < 4 ? X.f03 : X.f47, kx_)}, (t4_f2){X.a, X.a}, (t4_f2){X.bn, X.bf}); \
+      const t4_f2 ty_ = __builtin_elementwise_fma((t4_f2){T8_BYTE((c) < 4 ? Y.n03 : Y.n47, kx_), T8_BYTE((c) < 4 ? Y.f03 : Y.f47, kx_)}, (t4_f2){Y.a, Y.a}, (t4_f2){Y.bn, Y.bf}); \
+      const t4_f2 tz_ = __builtin_elementwise_fma((t4_f2){T8_BYTE((c) < 4 ? Z.n03 : Z.n47, kx_), T8_BYTE((c) < 4 ? Z.f03 : Z.f47, kx_)}, (t4_f2){Z.a, Z.a}, (t4_f2){Z.bn, Z.bf}); \
+      t0v = fmax_(fmax_(fmax_(0.0f, tx_.x), ty_.x), tz_.x); t1v = fmin_(t_max, fmin_(fmin_(tx_.y, ty_.y), tz_.y) * k2); }
 
 template <bool CHECK, int POLICY>
 __device__ __forceinline__ void t8_any_step(const DScene& S, T4Stack<uint32_t>& St, T4Lane& L, V3 o, V3 inv, float t_max) {
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(256) k_wf_trace8_any(DScene S, WfBuffers W, co
 /* ------------------------------------------------------------------ launch
  * LDS per workgroup decides the occupancy: the closest-hit kernel keeps `lds_entries` 8-byte levels per lane in LDS (2 KB per level
  * and workgroup), the any-hit kernel 4-byte levels; deeper levels live in `spill` (per lane, level-major). */
-Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_wg_oct) {
+Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_wg_oct, uint32_t knob_entries_oct) {
     Trace4Plan p; memset(&p, 0, sizeof(p));
     const uint32_t bound = S.quad_stack_bound ? S.quad_stack_bound : 1u;
     /* workgroups per CU the LDS stacks should leave room for.  Closest-hit: what its registers allow (96 VGPRs -> 5 waves per SIMD -> 5
@@ -587,7 +589,7 @@ Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest,
     /* eight-box occlusion records (k_wf_trace8_any): 4-byte entries, their own stack bound */
     if (S.oct && S.n_octs) {
         const uint32_t wg_8 = knob_wg_oct ? knob_wg_oct : 5u, budget_8 = ((158u * 1024u) / wg_8) & ~1023u, bound8 = S.oct_stack_bound ? S.oct_stack_bound : 1u;
-        const uint32_t e8 = budget_8 / (256u * 4u);
+        const uint32_t e8 = knob_entries_oct ? knob_entries_oct : budget_8 / (256u * 4u);
         p.entries_oct = e8 < bound8 ? e8 : bound8;
         p.spill_oct = bound8 - p.entries_oct;
         p.lds_oct = (size_t)p.entries_oct * 256u * 4u;

@@ -1184,7 +1184,7 @@ static uint32_t g_probe_bounce = 0;
 static int trace4_prepare(WavefrontState* st, const DScene& S) {
     st->t4_on = S.quad != nullptr && knob("FTN_TRACE4", 1) != 0;
     if (!st->t4_on) return FTN_OK;
-    st->t4 = trace4_plan(S, st->n_cu, knob("FTN_T4_ENTRIES", 0), knob("FTN_T4_ENTRIES_ANY", 0), knob("FTN_T4_WG", 0), knob("FTN_T4_WG_ANY", 0), knob("FTN_T8_WG", 0));
+    st->t4 = trace4_plan(S, st->n_cu, knob("FTN_T4_ENTRIES", 0), knob("FTN_T4_ENTRIES_ANY", 0), knob("FTN_T4_WG", 0), knob("FTN_T4_WG_ANY", 0), knob("FTN_T8_WG", 0), knob("FTN_T8_ENTRIES", 0));
     const size_t need_c = (size_t)st->t4.grid_closest * 256u * st->t4.spill_closest * sizeof(uint2);
     /* eight-box occlusion records for the any-hit rays of triangle-only scenes (FTN_T8=0: the four-box kernels trace them) */
     st->t8_on = st->t4.oct_ok && S.n_spheres == 0 && knob("FTN_T8", 1) != 0;

@@ -177,7 +177,7 @@ struct Trace4Plan {
     bool oct_ok; uint32_t entries_oct, spill_oct; size_t lds_oct; unsigned grid_oct;            /* k_wf_trace8_any (eight-box occlusion records) */
 };
 enum : int { T4K_CLOSEST = 0, T4K_ANY = 1, T4K_ANY_OCT = 2 };
-Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_wg_oct);
+Trace4Plan trace4_plan(const DScene& S, int n_cu, uint32_t knob_entries_closest, uint32_t knob_entries_any, uint32_t knob_wg_closest, uint32_t knob_wg_any, uint32_t knob_wg_oct, uint32_t knob_entries_oct);
 void launch_trace4(int kind, bool count, bool spheres, unsigned grid, size_t lds, uint32_t lds_entries, void* spill, hipStream_t stream, const DScene& S, const WfBuffers& W,
                    const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, DevStats* stats, uint32_t refill, uint32_t leaf_batch, uint32_t chunk, uint32_t burst, uint32_t any_policy, uint32_t spill_levels);
 

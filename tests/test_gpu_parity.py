@@ -653,6 +653,48 @@ def test_four_box_kernels_equal_the_oracle_on_ray_batches(gpu, orc_det, scene):
     assert np.array_equal(bits(full_g[:, :9]), bits(full_o[:, :9])) and np.array_equal(bits(full_g[:, 20:24]), bits(full_o[:, 20:24]))
 
 
+def test_occlusion_records_edge_cases(gpu, orc_det, monkeypatch):
+    """k_wf_trace8_any (eight-box occlusion records) where its special paths run: leaves of several primitives (coincident triangles share a
+    centroid, so the reference's build cannot split them: the leaf's exact box comes from `oct_xbox` and its primitives are walked in order),
+    flat and tiny triangles next to huge ones (step exponents, zero-extent axes), rays with direction components down to 1e-30 and origins
+    far outside the scene (beyond the range the conservative test is proven for: handed to the reference-order kernel), a two-level LDS
+    stack (every push spills).  Occlusion bit-equal to the oracle's and to the four-box kernel's."""
+    def make(be):
+        rng = np.random.default_rng(17)
+        b = SceneBuilder(be); b.material("matte")
+        P, N, F = scenes.rounded_cube_mesh()
+        b.shape("trianglemesh", P=P, N=N, indices=F)
+        tri = np.array([(2.0, 12.0, 1.0), (6.0, 12.0, 1.5), (3.0, 12.5, 6.0)], np.float32)
+        for k in range(5):                                           # five triangles with one centroid: a leaf of five primitives
+            b.shape("trianglemesh", P=np.roll(tri, k % 3, axis=0), indices=[0, 1, 2])
+        for _ in range(60):
+            c = rng.uniform(-25, 25, 3); sz = 10.0 ** rng.uniform(-3, 1.2)
+            Pt = (c + rng.normal(size=(3, 3)) * sz).astype(np.float32)
+            if rng.random() < 0.3: Pt[:, rng.integers(3)] = np.float32(c[0])          # flat along one axis
+            b.shape("trianglemesh", P=Pt, indices=[0, 1, 2])
+        b.shape("trianglemesh", P=[(-400, -400, -30), (400, -400, -30), (0, 500, -30)], indices=[0, 1, 2])     # one huge triangle
+        return b.create_scene()
+    sg, so = make(gpu), make(orc_det)
+    assert sg.info()["oct_bytes"] > 0
+    rays = _ray_mix(40000, 5)
+    rng = np.random.default_rng(6)
+    extra = _ray_mix(6000, 7)
+    extra[:2000, 3] = np.float32(1e-30) * np.sign(rng.normal(size=2000)).astype(np.float32)       # |1/d| = 1e30: outside the proven range
+    extra[2000:4000, 0:3] *= np.float32(1e13)                                                         # origins far away (|o| > 2^40)
+    extra[2000:4000, 3:6] = -extra[2000:4000, 0:3] / np.float32(1e12)                                 # ... aiming at the scene
+    extra[4000:, 5] = np.float32(3e-20)
+    rays = np.concatenate([rays, extra]).astype(np.float32)
+    occ_o, _ = so.intersect_test(rays)
+    occ, _ = sg.intersect_test(rays, stats=False)
+    assert np.array_equal(occ, occ_o) and 0 < occ.sum() < len(occ)
+    monkeypatch.setenv("FTN_T8", "0")                                # the four-box any-hit kernel on the same rays
+    occ4, _ = sg.intersect_test(rays, stats=False)
+    monkeypatch.delenv("FTN_T8")
+    assert np.array_equal(occ4, occ_o)
+    monkeypatch.setenv("FTN_T8_ENTRIES", "2")
+    assert np.array_equal(sg.intersect_test(rays, stats=False)[0], occ_o)
+
+
 def test_four_box_kernels_render_like_the_two_record_kernels(gpu, orc_det, monkeypatch):
     """the same render with the four-box kernels (default), with a two-level LDS stack (nearly every push spills to global memory), and
     with FTN_TRACE4=0 (round 1's kernels): one film, one set of counters; and it is the oracle's film"""
