@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 MEGA, WAVE = A.FTN_PIPELINE_MEGAKERNEL, A.FTN_PIPELINE_WAVEFRONT
 
 
-def make_recipe(seed, env_only=False):
-    rng = np.random.default_rng((5000 if env_only else 1000) + seed)
+def make_recipe(seed, env_only=False, tri_only=False):
+    rng = np.random.default_rng((5000 if env_only else 1000) + seed + (900000 if tri_only else 0))
     U = lambda a, b: float(rng.uniform(a, b))
     col = lambda lo=0.05, hi=0.95: tuple(float(x) for x in rng.uniform(lo, hi, 3))
     ops = []
@@ -67,7 +67,7 @@ def make_recipe(seed, env_only=False):
         if rng.random() < 0.25 and not env_only: ops.append(("area", col(2, 12)))
         if rng.random() < 0.3: ops.append(("reverse",))
         ops.extend(xform())
-        if rng.random() < 0.55:
+        if rng.random() < 0.55 and not tri_only:
             r = U(0.3, 1.1)
             kw = dict(radius=r)
             if rng.random() < 0.4: kw.update(zmin=-r * U(0.2, 1.0), zmax=r * U(0.2, 1.0), phimax=U(90, 360))
@@ -129,6 +129,13 @@ def test_random_scene(gpu, orc_det, seed):
 def test_random_environment_lit_scene(gpu, orc_det, seed):
     """same, with ONE infinite light and no emissive shape: the scenes the environment-only shading kernels take"""
     check_recipe(gpu, orc_det, make_recipe(seed, env_only=True), seed)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_triangle_only_scene(gpu, orc_det, seed):
+    """scenes without spheres (random meshes with degenerate, repeated and sliver triangles; every light kind): their shadow and MIS rays
+    walk the eight-box occlusion records (k_wf_trace8_any) -- multi-primitive leaves with explicit boxes, flat boxes, tiny next to large"""
+    check_recipe(gpu, orc_det, make_recipe(seed, env_only=seed % 3 == 0, tri_only=True), seed)
 
 
 def check_recipe(gpu, orc_det, recipe, seed):
