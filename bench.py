@@ -224,8 +224,8 @@ def roofline(args, cst, tot, n_steps, spp_per_step):
         profiled) -- divided by the launch duration measured LIVE in this run (HIP events on the launch stream).  frac <= 1 by construction;
       * algorithmic: bytes the walk asks the memory system for (128 B per four-box record + 48 B per triangle + ray i/o; SURVEY 8(d) restated
         for the records this kernel reads), most of which L1 / L2 serve -- a rate above the HBM peak only says the caches work;
-      * what binds: the PMC passes show the VALU pipes busy most of the launch and the HBM interface at a small fraction (valu_busy,
-        wave_cycles_waiting_on_memory) -- the kernel is instruction-issue bound, not bandwidth bound.
+      * what binds: neither the HBM roof nor instruction issue -- the latency of a ray's chain of dependent fetches at the occupancy the
+        registers and LDS stacks allow (`bound`, `binds`, `issue`).
     The same three figures are given for the other kernel groups of a step and for the step as a whole."""
     avg_ms = tot["trace_ms"] / max(tot["trace_launches"], 1)
     r = {"bound": "hbm", "kernel": "k_wf_trace4<closest> (128-byte four-box records)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
@@ -255,17 +255,23 @@ def roofline(args, cst, tot, n_steps, spp_per_step):
     r["l2_hit_rate"] = round(dk["l2_hit_rate"], 3)
     r["valu_busy"] = round(dk["valu_busy"], 3) if dk.get("valu_busy") is not None else None
     r["wave_cycles_waiting_on_memory"] = round(dk["wave_cycles_waiting_on_memory"], 3) if dk.get("wave_cycles_waiting_on_memory") is not None else None
-    # the roof that binds: VALU issue slots x lane utilisation.  valu_busy = the fraction of the launch's SIMD cycles in which a VALU instruction
-    # issues (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)); lanes_per_valu_inst = the lanes live in the average VALU instruction
+    # VALU issue slots x lane utilisation.  valu_busy = the fraction of the launch's SIMD cycles in which a VALU instruction issues
+    # (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)); lanes_per_valu_inst = the lanes live in the average VALU instruction
     # (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU); their product / 64 is the fraction of the chip's lane-issue slots that do work
     if dk.get("valu_busy") is not None and dk.get("lanes_per_valu_inst") is not None:
         r["issue"] = {"valu_busy": round(dk["valu_busy"], 3), "lanes_per_valu_inst": round(dk["lanes_per_valu_inst"], 1), "of_lanes": 64,
                       "frac": round(dk["valu_busy"] * dk["lanes_per_valu_inst"] / 64.0, 4)}
-        r["bound"] = "valu_issue" if dk["valu_busy"] > (r["frac"] or 0.0) else "hbm"
+    # What binds: neither roof.  Probes on this kernel (profiles/r03): +31 % dependent VALU instructions per
+    # record step cost +1.7 % time (not issue bound, whatever the busy counter says); records at half-line granularity or a third fewer
+    # record fetches per ray change nothing (not bytes, not the cached part of the chain).  A ray's walk is a chain of dependent fetches of
+    # which ~5.5 miss L2 (about four of them the triangle reads of its leaf tests); the launch takes chain latency x rays / rays in flight,
+    # and registers + LDS stacks fix the rays in flight (5 waves per SIMD).
+    r["bound"] = "memory_latency"
     r["hbm"] = {"achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"], "traffic": r["traffic"]}
-    r["binds"] = ("VALU issue: the kernel issues a VALU instruction in %.0f %% of its SIMD cycles with %.0f of 64 lanes live; the HBM interface runs at %.0f %% of its peak "
-                  "(achieved / peak / frac / traffic are the HBM figures the bench contract asks for; `issue` is the binding roof)"
-                  % (100.0 * (dk.get("valu_busy") or 0.0), dk.get("lanes_per_valu_inst") or 0.0, 100.0 * (r["frac"] or 0.0)))
+    r["binds"] = ("latency of each ray's chain of dependent fetches (~5.5 L2 misses per ray) at 5 waves per SIMD: the HBM interface runs at %.0f %% of its peak and a VALU "
+                  "instruction issues in %.0f %% of the SIMD cycles with %.0f of 64 lanes live, but +31 %% instructions per record step cost +1.7 %% time "
+                  "(profiles/r03/g_probe_closest_kernel_extra_valu.log); achieved / peak / frac / traffic are the HBM figures the bench contract asks for"
+                  % (100.0 * (r["frac"] or 0.0), 100.0 * (dk.get("valu_busy") or 0.0), dk.get("lanes_per_valu_inst") or 0.0))
     r["traffic_source"] = "profiles/%s/traffic.json (rocprofv3 --pmc over this command, production kernels only; FETCH_SIZE x 2 + WRITE_SIZE, cross-checked with TCC_EA0_RDREQ_128B x 128 B; counted where L2 meets the fabric, so lines the 256 MB Infinity Cache serves are included: an upper bound of the DRAM bytes)" % PROFILE_ROUND
     live = {"closest": tot["trace_ms"] / n_steps, "any_hit": tot["any_ms"] / n_steps, "shade": tot["shade_ms"] / n_steps, "sort": tot["sort_ms"] / n_steps}
     groups = {}
