@@ -268,10 +268,11 @@ def roofline(args, cst, tot, n_steps, spp_per_step):
     # and registers + LDS stacks fix the rays in flight (5 waves per SIMD).
     r["bound"] = "memory_latency"
     r["hbm"] = {"achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"], "traffic": r["traffic"]}
-    r["binds"] = ("latency of each ray's chain of dependent fetches (~5.5 L2 misses per ray) at 5 waves per SIMD: the HBM interface runs at %.0f %% of its peak and a VALU "
-                  "instruction issues in %.0f %% of the SIMD cycles with %.0f of 64 lanes live, but +31 %% instructions per record step cost +1.7 %% time "
-                  "(profiles/r03/g_probe_closest_kernel_extra_valu.log); achieved / peak / frac / traffic are the HBM figures the bench contract asks for"
-                  % (100.0 * (r["frac"] or 0.0), 100.0 * (dk.get("valu_busy") or 0.0), dk.get("lanes_per_valu_inst") or 0.0))
+    r["binds"] = ("co-limited at 5 waves per SIMD: the latency of each ray's chain of dependent fetches (~5.5 L2 misses per ray), VALU issue (%.0f %% of the SIMD "
+                  "cycles, %.0f of 64 lanes live) and the L1 path (~1.2 scattered lane-loads per clock and CU); the HBM interface runs at %.0f %% of its peak.  Taking "
+                  "pressure off one of the three put it on another: +31 %% instructions cost +1.7 %% time, a third fewer record fetches or triangle fetches cost "
+                  "nothing less (profiles/r03/g_*, h_*, j_*); achieved / peak / frac / traffic are the HBM figures the bench contract asks for"
+                  % (100.0 * (dk.get("valu_busy") or 0.0), dk.get("lanes_per_valu_inst") or 0.0, 100.0 * (r["frac"] or 0.0)))
     r["traffic_source"] = "profiles/%s/traffic.json (rocprofv3 --pmc over this command, production kernels only; FETCH_SIZE x 2 + WRITE_SIZE, cross-checked with TCC_EA0_RDREQ_128B x 128 B; counted where L2 meets the fabric, so lines the 256 MB Infinity Cache serves are included: an upper bound of the DRAM bytes)" % PROFILE_ROUND
     live = {"closest": tot["trace_ms"] / n_steps, "any_hit": tot["any_ms"] / n_steps, "shade": tot["shade_ms"] / n_steps, "sort": tot["sort_ms"] / n_steps}
     groups = {}
