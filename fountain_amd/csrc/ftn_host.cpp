@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <memory>
 #include <sched.h>
 #include <atomic>
 #include <limits>
@@ -207,6 +208,24 @@ static const float kFmax = 3.402823466e+38f;
 static Aabb aabb_empty() { Aabb b; for (int i = 0; i < 3; i++) { b.lo[i] = kFmax; b.hi[i] = -kFmax; } return b; }
 static void aabb_join_point(Aabb& b, V3 p) { b.lo[0] = fmin_(b.lo[0], p.x); b.lo[1] = fmin_(b.lo[1], p.y); b.lo[2] = fmin_(b.lo[2], p.z); b.hi[0] = fmax_(b.hi[0], p.x); b.hi[1] = fmax_(b.hi[1], p.y); b.hi[2] = fmax_(b.hi[2], p.z); }
 
+/* ------------------------------------------------------------------ host threads for the per-element passes of ftn_scene_create
+ * (this process's share of the host: bvh_default_threads; FTN_BVH_THREADS overrides; at most 32).  f(begin, end) over [0, n) in
+ * contiguous blocks: every pass that uses it writes each element from that element's inputs alone, so the result does not depend on
+ * the number of threads. */
+static int bvh_default_threads();
+static int host_threads() {
+    int n = bvh_default_threads();
+    if (const char* e = getenv("FTN_BVH_THREADS")) n = atoi(e);
+    return std::max(1, std::min(n, 32));
+}
+template <class F> static void parallel_for(size_t n, F f) {
+    const int nt = (int)std::min<size_t>((size_t)host_threads(), n / 65536 + 1);
+    if (nt <= 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&, t]() { f(n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt); });
+    for (auto& x : th) x.join();
+}
+
 struct BvhBuilder {
     const std::vector<Aabb>& bounds;
     std::vector<float> own_centroid; std::vector<uint32_t> own_order;
@@ -218,10 +237,10 @@ struct BvhBuilder {
     BvhBuilder(const std::vector<Aabb>& b, std::vector<float>& c, std::vector<uint32_t>& o, size_t base) : bounds(b), centroid(c), order(o), leaf_base(base) {}
     explicit BvhBuilder(const std::vector<Aabb>& b) : bounds(b), centroid(own_centroid), order(own_order) {
         size_t n = b.size(); centroid.resize(3 * n); order.resize(n);
-        for (size_t i = 0; i < n; i++) {
+        parallel_for(n, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) {
             order[i] = (uint32_t)i;
             for (int k = 0; k < 3; k++) centroid[3 * i + k] = b[i].lo[k] + ((b[i].hi[k] - b[i].lo[k]) / 2.0f);   /* Bounds3::centroid bounds.rs:160-162 */
-        }
+        } });
     }
     void build(size_t lo, size_t hi, uint32_t depth) {               /* recursive_build :66-120 + flatten_tree :133-158 */
         if (depth > max_depth) max_depth = depth;
@@ -399,19 +418,31 @@ static void build_quads(const std::vector<ftn_bvh_node>& nodes, QuadBvh* out) {
         }
         slot[6] = ftn_det::u2f(link); slot[7] = ftn_det::u2f(meta);
     };
+    /* the records: each from the nodes alone (host threads) */
+    parallel_for(owners.size(), [&](size_t q0, size_t q1) {
+        for (size_t q = q0; q < q1; q++) {
+            const uint32_t r = owners[q];
+            const uint32_t ch[2] = {r + 1u, nodes[r].idx};
+            float* R = &out->rec[(size_t)32 * q];
+            for (int k = 0; k < 2; k++) {
+                const ftn_bvh_node& c = nodes[ch[k]];
+                /* slot 0's meta: one-hot axes of A (byte 0), R (byte 1), B (byte 2); a leaf child has no axis (its pair has one member) */
+                const uint32_t axes = k == 0 ? ((c.is_leaf ? 0u : (1u << c.axis)) | ((1u << nodes[r].axis) << 8) | ((nodes[ch[1]].is_leaf ? 0u : (1u << nodes[ch[1]].axis)) << 16)) : 0u;
+                if (c.is_leaf) { put(R + 16 * k, &c, ch[k], axes); put(R + 16 * k + 8, nullptr, 0, 0u); }
+                else { const uint32_t g0 = ch[k] + 1u, g1 = c.idx; put(R + 16 * k, &nodes[g0], g0, axes); put(R + 16 * k + 8, &nodes[g1], g1, 0u); }
+            }
+        }
+    });
+    /* the stack bound, bottom up */
     for (size_t q = owners.size(); q-- > 0;) {                                  /* children have larger ids: their bounds are known */
         const uint32_t r = owners[q];
         const uint32_t ch[2] = {r + 1u, nodes[r].idx};
-        float* R = &out->rec[(size_t)32 * q];
         uint32_t valid = 0, deepest = 0;
         for (int k = 0; k < 2; k++) {
             const ftn_bvh_node& c = nodes[ch[k]];
-            /* slot 0's meta: one-hot axes of A (byte 0), R (byte 1), B (byte 2); a leaf child has no axis (its pair has one member) */
-            const uint32_t axes = k == 0 ? ((c.is_leaf ? 0u : (1u << c.axis)) | ((1u << nodes[r].axis) << 8) | ((nodes[ch[1]].is_leaf ? 0u : (1u << nodes[ch[1]].axis)) << 16)) : 0u;
-            if (c.is_leaf) { put(R + 16 * k, &c, ch[k], axes); put(R + 16 * k + 8, nullptr, 0, 0u); valid += 1; }
+            if (c.is_leaf) valid += 1;
             else {
-                const uint32_t g0 = ch[k] + 1u, g1 = c.idx;
-                put(R + 16 * k, &nodes[g0], g0, axes); put(R + 16 * k + 8, &nodes[g1], g1, 0u); valid += 2;
+                const uint32_t g0 = ch[k] + 1u, g1 = c.idx; valid += 2;
                 if (!nodes[g0].is_leaf) deepest = std::max(deepest, bound[owner_id[g0]]);
                 if (!nodes[g1].is_leaf) deepest = std::max(deepest, bound[owner_id[g1]]);
             }
@@ -463,7 +494,30 @@ static void build_octs(const std::vector<ftn_bvh_node>& nodes, const std::vector
     if (recs.size() >= (1u << 24)) return;                                       /* links are byte offsets below 2^31 */
     out->rec.assign((size_t)32 * recs.size(), 0u);
     std::vector<uint32_t> bound(recs.size(), 0);
-    for (size_t q = recs.size(); q-- > 0;) {
+    /* which leaf children carry an explicit box (bit k of xmask[q]): every leaf that is not a single triangle whose node box is the min / max
+     * of its vertices.  Their xbox slots are numbered in the order records are finished (last record first, children in slot order) */
+    auto leaf_is_implicit = [&](const ftn_bvh_node& c) {
+        if (c.n_prims != 1 || geom.empty()) return false;
+        const float4 g0 = geom[(size_t)FTN_GS * c.idx], g1 = geom[(size_t)FTN_GS * c.idx + 1], g2 = geom[(size_t)FTN_GS * c.idx + 2];
+        if (ftn_det::f2u(g0.w) & GF_KIND_SPHERE) return false;
+        const float lo[3] = {std::min(std::min(g0.x, g1.x), g2.x), std::min(std::min(g0.y, g1.y), g2.y), std::min(std::min(g0.z, g1.z), g2.z)};
+        const float hi[3] = {std::max(std::max(g0.x, g1.x), g2.x), std::max(std::max(g0.y, g1.y), g2.y), std::max(std::max(g0.z, g1.z), g2.z)};
+        for (int a = 0; a < 3; a++) if (ftn_det::f2u(lo[a]) != ftn_det::f2u(c.bmin[a]) || ftn_det::f2u(hi[a]) != ftn_det::f2u(c.bmax[a])) return false;
+        return true;
+    };
+    std::vector<uint8_t> xmask(recs.size(), 0);
+    parallel_for(recs.size(), [&](size_t q0, size_t q1) {
+        for (size_t q = q0; q < q1; q++) {
+            const Rec& R = recs[q]; uint8_t m = 0;
+            for (int k = 0; k < R.n; k++) { const ftn_bvh_node& c = nodes[R.child[k]]; if (c.is_leaf && !leaf_is_implicit(c)) m |= (uint8_t)(1u << k); }
+            xmask[q] = m;
+        }
+    });
+    std::vector<uint32_t> xbase(recs.size(), 0);
+    { uint32_t run = 0; for (size_t q = recs.size(); q-- > 0;) { xbase[q] = run; run += (uint32_t)__builtin_popcount(xmask[q]); } out->xbox.assign(2 * (size_t)run, make_float4(0.0f, 0.0f, 0.0f, 0.0f)); }
+    /* the records: each from the nodes alone (host threads) */
+    parallel_for(recs.size(), [&](size_t q0, size_t q1) {
+    for (size_t q = q0; q < q1; q++) {
         const Rec& R = recs[q];
         const ftn_bvh_node& root = nodes[R.root];
         uint32_t* W = &out->rec[(size_t)32 * q];
@@ -488,7 +542,7 @@ static void build_octs(const std::vector<ftn_bvh_node>& nodes, const std::vector
             memcpy(&W[a], &root.bmin[a], 4);
         }
         W[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
-        uint32_t deepest = 0;
+        uint32_t xi = xbase[q];
         for (int k = 0; k < 8; k++) {
             uint32_t link = 0xffffffffu; uint32_t qb[6] = {255u, 0u, 255u, 0u, 255u, 0u};
             if (k < R.n) {
@@ -503,29 +557,24 @@ static void build_octs(const std::vector<ftn_bvh_node>& nodes, const std::vector
                     if (qh > 255.0) qh = 255.0;                                   /* (cannot happen: the step was chosen with slack) */
                     qb[2 * a] = (uint32_t)ql; qb[2 * a + 1] = (uint32_t)qh;
                 }
-                if (!c.is_leaf) { link = rec_of[ci] * 128u; deepest = std::max(deepest, bound[rec_of[ci]]); }
+                if (!c.is_leaf) link = rec_of[ci] * 128u;
+                else if (!((xmask[q] >> k) & 1u)) link = 0x80000000u | c.idx;         /* a single triangle whose node box is the min / max of its vertices */
                 else {
-                    bool implicit_box = c.n_prims == 1 && !geom.empty();
-                    if (implicit_box) {                                           /* a single triangle whose node box is the min / max of its vertices */
-                        const float4 g0 = geom[(size_t)FTN_GS * c.idx], g1 = geom[(size_t)FTN_GS * c.idx + 1], g2 = geom[(size_t)FTN_GS * c.idx + 2];
-                        if (ftn_det::f2u(g0.w) & GF_KIND_SPHERE) implicit_box = false;
-                        else {
-                            const float lo[3] = {std::min(std::min(g0.x, g1.x), g2.x), std::min(std::min(g0.y, g1.y), g2.y), std::min(std::min(g0.z, g1.z), g2.z)};
-                            const float hi[3] = {std::max(std::max(g0.x, g1.x), g2.x), std::max(std::max(g0.y, g1.y), g2.y), std::max(std::max(g0.z, g1.z), g2.z)};
-                            for (int a = 0; a < 3; a++) if (ftn_det::f2u(lo[a]) != ftn_det::f2u(c.bmin[a]) || ftn_det::f2u(hi[a]) != ftn_det::f2u(c.bmax[a])) implicit_box = false;
-                        }
-                    }
-                    if (implicit_box) link = 0x80000000u | c.idx;
-                    else {
-                        link = 0xc0000000u | (uint32_t)(out->xbox.size() / 2);
-                        out->xbox.push_back(make_float4(c.bmin[0], c.bmin[1], c.bmin[2], ftn_det::u2f(c.idx)));
-                        out->xbox.push_back(make_float4(c.bmax[0], c.bmax[1], c.bmax[2], 0.0f));
-                    }
+                    link = 0xc0000000u | xi;
+                    out->xbox[2 * (size_t)xi] = make_float4(c.bmin[0], c.bmin[1], c.bmin[2], ftn_det::u2f(c.idx));
+                    out->xbox[2 * (size_t)xi + 1] = make_float4(c.bmax[0], c.bmax[1], c.bmax[2], 0.0f);
+                    xi++;
                 }
             }
             W[4 + k] = link;
             for (int j = 0; j < 6; j++) W[12 + 2 * j + (k >> 2)] |= qb[j] << (8 * (k & 3));
         }
+    }
+    });
+    /* the stack bound, bottom up */
+    for (size_t q = recs.size(); q-- > 0;) {
+        const Rec& R = recs[q]; uint32_t deepest = 0;
+        for (int k = 0; k < R.n; k++) if (!nodes[R.child[k]].is_leaf) deepest = std::max(deepest, bound[rec_of[R.child[k]]]);
         bound[q] = (uint32_t)(R.n - 1) + deepest;
     }
     if (out->xbox.size() / 2 >= (1u << 30) || nodes.size() >= (1u << 30)) return;
@@ -613,7 +662,7 @@ static int validate_desc(const ftn_scene_desc* d) {
 static int build_host_scene(const ftn_scene_desc* d, HostScene* hs) {
     int rc = validate_desc(d); if (rc) return rc;
     std::vector<Aabb> pb(d->n_prims);
-    for (uint32_t i = 0; i < d->n_prims; i++) pb[i] = prim_bounds(d, d->prims[i]);
+    parallel_for(d->n_prims, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) pb[i] = prim_bounds(d, d->prims[i]); });
     hs->world = aabb_empty();
     if (d->n_prims) {
         BvhBuilder b(pb);
@@ -752,11 +801,22 @@ struct ftn_scene {
     }
 };
 
+/* FTN_SCENE_DEBUG: wall time of the phases of ftn_scene_create on stderr */
+struct PhaseClock {
+    bool on; std::chrono::steady_clock::time_point t;
+    PhaseClock() : on(getenv("FTN_SCENE_DEBUG") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ftn scene] %-44s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n;
+    }
+};
 static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     const HostScene& hs = sc->host;
+    PhaseClock clk;
     const size_t np = hs.order.size();
     std::vector<float4> nodes(2 * hs.nodes.size());
-    for (size_t i = 0; i < hs.nodes.size(); i++) {
+    parallel_for(hs.nodes.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) {
         const ftn_bvh_node& n = hs.nodes[i];
         /* slab pairs first: the x and y (min, max) pairs, then the z pair with the two index words (see ftn_device.h) */
         nodes[2 * i] = make_float4(n.bmin[0], n.bmax[0], n.bmin[1], n.bmax[1]);
@@ -764,7 +824,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
          * meta: n_prims | one-hot split axis << 16 (matches the ray's dir_is_neg bits) | leaf << 24 */
         const uint32_t link = n.is_leaf ? n.idx : n.idx * 32u;
         nodes[2 * i + 1] = make_float4(n.bmin[2], n.bmax[2], ftn_det::u2f(link), ftn_det::u2f((uint32_t)n.n_prims | ((1u << n.axis) << 16) | ((uint32_t)n.is_leaf << 24)));
-    }
+    } });
     /* two-box records (see DScene::fat): one per interior node, numbered in DFS order */
     if (hs.nodes.size() >= (1u << 27)) return fail(FTN_ERR_UNSUPPORTED, "more than 2^27 BVH nodes (node links are 32-bit byte offsets)");
     /* only the legacy any-hit kernel (k_wf_trace_any2: FTN_TRACE4=0, or a scene without four-box records) reads them: 639 MB at 10 M
@@ -792,7 +852,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     std::vector<int> prim_light(np, -1);
     for (size_t l = 0; l < hs.light_prim.size(); l++) if (hs.light_prim[l] >= 0) prim_light[hs.light_prim[l]] = (int)l;
     std::vector<float4> geom((size_t)FTN_GS * np); std::vector<uint4> info(2 * np);
-    for (size_t i = 0; i < np; i++) {
+    parallel_for(np, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) {
         const ftn_prim& p = d->prims[hs.order[i]];
         uint32_t fl = 0;
         if (p.shape_kind == FTN_SHAPE_SPHERE) {
@@ -814,59 +874,58 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             info[2 * i + 1] = make_uint4(vi[0], vi[1], vi[2], p.shape_index);
         }
         info[2 * i] = make_uint4((uint32_t)p.material, (uint32_t)prim_light[i], fl, 0);
-    }
+    } });
+    clk.mark("node records, leaf-test records (host)");
     int rc;
     if ((rc = sc->nodes.upload(nodes.data(), nodes.size()))) return rc;
+    clk.mark("upload nodes");
     /* two-box record links are 31-bit byte offsets: beyond 2^25 interior nodes the any-hit kernel falls back to the plain node walk */
     if (n_fat && n_fat < (1u << 25)) { if ((rc = sc->fat.upload(fat.data(), fat.size()))) return rc; }
     /* four-box records (DScene::quad): what the production traversal kernels walk.  FTN_QUAD=0: not built (the two-record kernels run) */
     uint32_t n_quads = 0, quad_bound = 0;
-    {
-        const char* knob = getenv("FTN_QUAD");
-        if (!knob || atoi(knob) != 0) {
-            QuadBvh qb; build_quads(hs.nodes, &qb);
-            if (qb.ok && qb.n_records) {
-                if ((rc = sc->quad.upload(reinterpret_cast<const float4*>(qb.rec.data()), (size_t)8 * qb.n_records))) return rc;
-                n_quads = qb.n_records; quad_bound = qb.stack_bound;
-            }
+    if (!env_is("FTN_QUAD", 0)) {
+        QuadBvh qb; build_quads(hs.nodes, &qb);
+        if (qb.ok && qb.n_records) {
+            if ((rc = sc->quad.upload(reinterpret_cast<const float4*>(qb.rec.data()), (size_t)8 * qb.n_records))) return rc;
+            n_quads = qb.n_records; quad_bound = qb.stack_bound;
         }
     }
+    clk.mark("four-box records (host + upload)");
     /* eight-box occlusion records (DScene::oct): triangle-only scenes with four-box records (the kernel hands its exceptional rays to the
-     * same fallback).  FTN_OCT=0: not built (k_wf_trace4_any_dual traces the shadow rays) */
+     * same fallback).  FTN_OCT=0: not built (the four-box any-hit kernel traces the shadow rays) */
     uint32_t n_octs = 0, oct_bound = 0;
-    {
-        const char* knob = getenv("FTN_OCT");
-        if ((!knob || atoi(knob) != 0) && n_quads != 0 && d->n_spheres == 0) {
-            OctBvh ob; build_octs(hs.nodes, geom, &ob);
-            if (ob.ok && ob.n_records) {
-                if ((rc = sc->oct.upload(reinterpret_cast<const uint4*>(ob.rec.data()), (size_t)8 * ob.n_records))) return rc;
-                if (!ob.xbox.empty() && (rc = sc->oct_xbox.upload(ob.xbox.data(), ob.xbox.size()))) return rc;
-                n_octs = ob.n_records; oct_bound = ob.stack_bound;
-            }
+    if (!env_is("FTN_OCT", 0) && n_quads != 0 && d->n_spheres == 0) {
+        OctBvh ob; build_octs(hs.nodes, geom, &ob);
+        if (ob.ok && ob.n_records) {
+            if ((rc = sc->oct.upload(reinterpret_cast<const uint4*>(ob.rec.data()), (size_t)8 * ob.n_records))) return rc;
+            if (!ob.xbox.empty() && (rc = sc->oct_xbox.upload(ob.xbox.data(), ob.xbox.size()))) return rc;
+            n_octs = ob.n_records; oct_bound = ob.stack_bound;
         }
     }
-    /* shading records (DScene::srec): one 128-byte line per primitive with everything make_interaction reads.  FTN_SREC=0: not built */
-    {
-        const char* knob = getenv("FTN_SREC");
-        if ((!knob || atoi(knob) != 0) && np != 0 && (uint64_t)np * 128u <= (16ull << 30)) {
-            std::vector<float4> rec(8 * np, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-            for (size_t i = 0; i < np; i++) {
-                float4* R = &rec[8 * i];
-                const uint4 pi = info[2 * i], vi = info[2 * i + 1];
-                R[0] = geom[FTN_GS * i]; R[1] = geom[FTN_GS * i + 1]; R[2] = geom[FTN_GS * i + 2];
-                R[1].w = ftn_det::u2f(pi.x); R[2].w = ftn_det::u2f(pi.y); R[6].w = ftn_det::u2f(vi.w);
-                const uint32_t fl = ftn_det::f2u(R[0].w);
-                if (fl & GF_KIND_SPHERE) continue;
-                const uint32_t v[3] = {vi.x, vi.y, vi.z};
-                if (fl & GF_HAS_NORMALS) for (int k = 0; k < 3; k++) { R[3 + k].x = d->N[3 * (size_t)v[k]]; R[3 + k].y = d->N[3 * (size_t)v[k] + 1]; R[3 + k].z = d->N[3 * (size_t)v[k] + 2]; }
-                if (fl & GF_HAS_UVS) {
-                    R[3].w = d->UV[2 * (size_t)v[0]]; R[4].w = d->UV[2 * (size_t)v[0] + 1]; R[5].w = d->UV[2 * (size_t)v[1]];
-                    R[6].x = d->UV[2 * (size_t)v[1] + 1]; R[6].y = d->UV[2 * (size_t)v[2]]; R[6].z = d->UV[2 * (size_t)v[2] + 1];
-                }
+    clk.mark("eight-box records (host + upload)");
+    /* shading records (DScene::srec): one 128-byte line per primitive with everything make_interaction reads.  FTN_SREC=0: not built.
+     * (Building these three arrays on a worker while this thread uploads the previous one was measured: no faster -- the pageable
+     * host-to-device copies and the builders want the same memory bandwidth.) */
+    if (!env_is("FTN_SREC", 0) && np != 0 && (uint64_t)np * 128u <= (16ull << 30)) {
+        std::unique_ptr<float4[]> rec(new float4[8 * np]);          /* (not value-initialised: every word is written below) */
+        parallel_for(np, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) {
+            float4* R = &rec[8 * i];
+            for (int k = 3; k < 8; k++) R[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const uint4 pi = info[2 * i], vi = info[2 * i + 1];
+            R[0] = geom[FTN_GS * i]; R[1] = geom[FTN_GS * i + 1]; R[2] = geom[FTN_GS * i + 2];
+            R[1].w = ftn_det::u2f(pi.x); R[2].w = ftn_det::u2f(pi.y); R[6].w = ftn_det::u2f(vi.w);
+            const uint32_t fl = ftn_det::f2u(R[0].w);
+            if (fl & GF_KIND_SPHERE) continue;
+            const uint32_t v[3] = {vi.x, vi.y, vi.z};
+            if (fl & GF_HAS_NORMALS) for (int k = 0; k < 3; k++) { R[3 + k].x = d->N[3 * (size_t)v[k]]; R[3 + k].y = d->N[3 * (size_t)v[k] + 1]; R[3 + k].z = d->N[3 * (size_t)v[k] + 2]; }
+            if (fl & GF_HAS_UVS) {
+                R[3].w = d->UV[2 * (size_t)v[0]]; R[4].w = d->UV[2 * (size_t)v[0] + 1]; R[5].w = d->UV[2 * (size_t)v[1]];
+                R[6].x = d->UV[2 * (size_t)v[1] + 1]; R[6].y = d->UV[2 * (size_t)v[2]]; R[6].z = d->UV[2 * (size_t)v[2] + 1];
             }
-            if ((rc = sc->srec.upload(rec.data(), rec.size()))) return rc;
-        }
+        } });
+        if ((rc = sc->srec.upload(rec.get(), 8 * np))) return rc;
     }
+    clk.mark("shading records (host + upload)");
     /* leaf-test records: the shading records' first 48 bytes in triangle-only scenes (DScene::geom_stride = 8), the dense array otherwise */
     const bool geom_in_srec = sc->srec.p != nullptr && d->n_spheres == 0 && !env_is("FTN_GEOM", 1);
     if (!geom_in_srec && (rc = sc->geom.upload(geom.data(), geom.size()))) return rc;
@@ -898,6 +957,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
         if (!textured) material_finalize(mats[i]);
     }
     if ((rc = sc->materials.upload(mats.data(), mats.size()))) return rc;
+    clk.mark("leaf-test / attribute arrays, spheres, materials");
     {   /* shading class per primitive (DScene::prim_class) */
         std::vector<unsigned char> cls(np);
         for (size_t i = 0; i < np; i++) { const int m = (int)info[2 * i].x; cls[i] = (unsigned char)(m < 0 || (size_t)m >= mats.size() ? 7u : std::min<uint32_t>(2u + mats[(size_t)m].type, 7u)); }
@@ -982,6 +1042,7 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
     }
     if ((rc = sc->lights.upload(lights.data(), lights.size()))) return rc;
     if ((rc = sc->inf_lights.upload(inf.data(), inf.size()))) return rc;
+    clk.mark("classes, lights, environment tables, textures");
     DScene& D = sc->d; memset(&D, 0, sizeof(D));
     D.nodes = sc->nodes.p; D.geom = geom_in_srec ? sc->srec.p : sc->geom.p; D.geom_stride = geom_in_srec ? 8u : (uint32_t)FTN_GS; D.prim_info = sc->prim_info.p; D.N = sc->N.p; D.UV = sc->UV.p; D.T = sc->T.p; D.spheres = sc->spheres.p;
     D.materials = sc->materials.p; D.lights = sc->lights.p; D.inf_lights = sc->inf_lights.p;
@@ -1086,7 +1147,9 @@ int ftn_scene_create(const ftn_scene_desc* d, int device, ftn_scene** out) {
     int rc = set_device(device); if (rc) return rc;
     ftn_scene* sc = new ftn_scene();
     sc->device = device;
+    PhaseClock clk;
     rc = build_host_scene(d, &sc->host);
+    clk.mark("host scene: bounds, BVH, lights");
     if (!rc && sc->host.max_depth > 64) rc = fail(FTN_ERR_BVH_TOO_DEEP, "BVH deeper than the reference's 64-entry traversal stack (bvh.rs:168)");
     if (!rc) rc = upload_scene(d, sc);
     if (rc) { delete sc; return rc; }
