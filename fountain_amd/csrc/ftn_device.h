@@ -252,6 +252,9 @@ __device__ inline bool tri_uv_degenerate_reject(const DScene& S, int prim, V3 p0
 __device__ inline bool sphere_clipped(const DSphere& s, V3 p, float phi) {
     return (s.z_min > -s.radius && p.z < s.z_min) || (s.z_max < s.radius && p.z > s.z_max) || phi > s.phi_max;
 }
+/* FILL = false: hit / miss and t only (si is not looked at).  A template instead of a test of `si` against null: the address of a private
+ * variable compared with null keeps the variable -- the caller's whole DSI -- in scratch memory (an alloca with an icmp user is not promoted) */
+template <bool FILL = true>
 FTN_DEV_NOINLINE bool sphere_intersect(const DSphere& s, const DRay& wr, float* t_out, DSI* si, DSIX* ex = nullptr) {
     V3 o_err, d_err;
     V3 ot = m4_point_exact_to_err(s.w2o, wr.o, &o_err);      /* Ray::tf_exact_to_err transform.rs:287-300 */
@@ -286,7 +289,7 @@ FTN_DEV_NOINLINE bool sphere_intersect(const DSphere& s, const DRay& wr, float* 
         if (sphere_clipped(s, p, phi)) return false;
     }
     *t_out = th.v;
-    if (!si) return true;
+    if (!FILL) return true;
     float theta = ftn_det::acosf_det(clampf(p.z / s.radius, -1.0f, 1.0f));
     float z_radius = sqrtf(p.x * p.x + p.y * p.y);
     float inv_zr = 1.0f / z_radius;
@@ -353,7 +356,7 @@ __device__ inline bool traverse(const DScene& S, DRay& ray, const LdsStack& st, 
                     if (COUNT) tc->prims++;
                     const uint32_t fl = __float_as_uint(g0.w);
                     float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool h;
-                    if (fl & GF_KIND_SPHERE) h = sphere_intersect(S.spheres[__float_as_uint(g1.w)], ray, &t, nullptr);
+                    if (fl & GF_KIND_SPHERE) h = sphere_intersect<false>(S.spheres[__float_as_uint(g1.w)], ray, &t, nullptr);
                     else {
                         V3 p0(g0.x, g0.y, g0.z), p1(g1.x, g1.y, g1.z), p2(g2.x, g2.y, g2.z);
                         h = tri_hit(ray.o, ray.d, ray.t_max, p0, p1, p2, &t, &b0, &b1, &b2);

@@ -120,7 +120,7 @@ __device__ inline bool prim_hit(const DScene& S, uint32_t prim, float4 g0, float
     float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f; bool hh = false;
     if (SPHERES && (fl & GF_KIND_SPHERE)) {
         DRay r; r.o = o; r.d = dorig; r.t_max = t_max; r.time = 0.0f;
-        hh = sphere_intersect(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
+        hh = sphere_intersect<false>(S.spheres[__float_as_uint(g1.w)], r, &t, nullptr);
     } else {
         /* Triangle::intersect hit test (triangle.rs:183-268) with the per-ray constants hoisted */
         /* permute_point(p - o, kx, ky, kz) with (kx, ky, kz) = (kz+1, kz+2, kz) mod 3, as selects on registers */
