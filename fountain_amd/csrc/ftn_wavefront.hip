@@ -405,6 +405,9 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
 #ifndef FTN_SHADE_MIN_WAVES
 #define FTN_SHADE_MIN_WAVES 1
 #endif
+#ifndef FTN_SHADE_WAVES_NOBSDF
+#define FTN_SHADE_WAVES_NOBSDF 4      /* finished paths / misses (5 waves: 96 registers, no scratch -- measured equal: 99.3 against 99.5 ms of shading) */
+#endif
 #ifndef FTN_SHADE_WAVES_MATTE
 #define FTN_SHADE_WAVES_MATTE 3
 #endif
@@ -418,7 +421,7 @@ __device__ inline DHit load_hit(const WfBuffers& W, uint32_t r) {
  * loads instead of one gather per field and lane) and the point / distant / area-light code is compiled out; every value computed
  * is the one the generic kernel computes for such a scene. */
 template <bool TEX, int MT, bool ENV>
-__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? 4 : (MT == 0 ? FTN_SHADE_WAVES_MATTE : FTN_SHADE_WAVES_OTHER)))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask, uint32_t first /* 1: the pass right behind k_wf_generate -- every path is fresh */) {
+__global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == -2 ? FTN_SHADE_WAVES_NOBSDF : (MT == 0 ? FTN_SHADE_WAVES_MATTE : FTN_SHADE_WAVES_OTHER)))) k_wf_shade(RenderParams P, WfBuffers W, int in_q, uint32_t class_mask, uint32_t first /* 1: the pass right behind k_wf_generate -- every path is fresh */) {
     const DScene& S = P.S;
     /* virtual, 256-aligned concatenation of the selected class segments: a workgroup never straddles two classes */
     uint32_t cbase[WF_NCLASS + 1], ccnt[WF_NCLASS];
