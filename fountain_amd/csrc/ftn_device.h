@@ -59,6 +59,12 @@ struct DLight {
      * 1024^2 map, cache resident -- find_interval looks there first and then inside ONE 32-entry block of the 4 MB table instead of
      * bisecting across it (NULL: a CDF was not monotone, e.g. NaN texels; the plain search is used) */
     const float* cond_coarse; const float* marg_coarse;
+    /* Cell records (square maps; NULL: not built): one 128-byte line per cell (u, v) of the map with what every lookup around that cell
+     * reads -- its 3 x 3 texel neighbourhood (wrapped like env_texel; 27 floats, texel (dx, dy) at 3 * ((dy + 1) * 3 + dx + 1)) and the
+     * distribution's function value of the cell (float 27).  A light sample reads ONE line behind its CDF search (function value +
+     * the four texels of Le) instead of three, the pdf of a BSDF-sampled direction and the Le of the same direction one bounce later
+     * read the same line: env_cell_* below.  128 MB for a 1024^2 map. */
+    const float4* cells;
 };
 
 /* one ftn_image with its MIP pyramid (mipmap.rs:78-145): level l is lw[l] x lh[l] float4 texels starting at texels[off[l]] */
@@ -877,6 +883,27 @@ __host__ __device__ inline Rgb env_lookup(const DLight& L, V2 st) {      /* tria
     return env_texel(L, s0, t0) * (1.0f - ds) * (1.0f - dt) + env_texel(L, s0, t0 + 1) * (1.0f - ds) * dt +
            env_texel(L, s0 + 1, t0) * ds * (1.0f - dt) + env_texel(L, s0 + 1, t0 + 1) * ds * dt;
 }
+/* env_lookup out of the cell record centred at (cx, cy): the same four texels, the same weights, the same expression.  false: the
+ * lookup's 2 x 2 block is not inside this cell's neighbourhood (the caller then reads the plain texel table) */
+__device__ inline bool env_cell_lookup(const DLight& L, V2 st, int cx, int cy, Rgb* out) {
+    float s = st.x * (float)L.env_w - 0.5f, t = st.y * (float)L.env_h - 0.5f;
+    int s0 = f2i_sat(floorf(s)), t0 = f2i_sat(floorf(t));
+    float ds = s - (float)s0, dt = t - (float)t0;
+    const int dx = s0 - cx, dy = t0 - cy;                       /* -1 or 0 for the cell that contains st */
+    if (dx < -1 || dx > 0 || dy < -1 || dy > 0) return false;
+    const float* c = reinterpret_cast<const float*>(L.cells + 8 * ((size_t)cy * L.env_w + (size_t)cx)) + 3 * ((dy + 1) * 3 + dx + 1);
+    const Rgb t00(c[0], c[1], c[2]), t10(c[3], c[4], c[5]), t01(c[9], c[10], c[11]), t11(c[12], c[13], c[14]);
+    *out = t00 * (1.0f - ds) * (1.0f - dt) + t01 * (1.0f - ds) * dt + t10 * ds * (1.0f - dt) + t11 * ds * dt;
+    return true;
+}
+__device__ inline float env_cell_func(const DLight& L, uint32_t cx, uint32_t cy) {
+    return reinterpret_cast<const float*>(L.cells + 8 * ((size_t)cy * L.env_w + (size_t)cx))[27];
+}
+/* the cell that contains st = (u, v) in [0, 1]^2 */
+__device__ inline void env_cell_of(const DLight& L, V2 st, int* cx, int* cy) {
+    int x = f2i_sat(floorf(st.x * (float)L.env_w)), y = f2i_sat(floorf(st.y * (float)L.env_h));
+    *cx = x < 0 ? 0 : (x > (int)L.env_w - 1 ? (int)L.env_w - 1 : x); *cy = y < 0 ? 0 : (y > (int)L.env_h - 1 ? (int)L.env_h - 1 : y);
+}
 __device__ inline uint32_t search_cdf(const float* cdf, uint32_t size, float u) {   /* sampling.rs:66-81 */
     uint32_t first = 0, len = size;
     while (len > 0) {
@@ -905,17 +932,19 @@ __device__ inline uint32_t search_cdf_blocked(const float* cdf, const float* coa
     int v = (int)first - 1, top = (int)size - 2;
     return (uint32_t)(v < 0 ? 0 : (v > top ? top : v));
 }
+/* (func == NULL: *pdf is left to the caller, who has the function value from somewhere else -- the cell record) */
 __device__ inline void dist1d_sample(const float* func, const float* cdf, float integral, uint32_t n, float u, float* x, float* pdf, uint32_t* idx, const float* coarse = nullptr) {
     uint32_t i = (coarse && n > 0u) ? search_cdf_blocked(cdf, coarse, n + 1, u) : search_cdf(cdf, n + 1, u);
     float du = u - cdf[i];
     if (cdf[i + 1] - cdf[i] > 0.0f) du /= cdf[i + 1] - cdf[i];
-    *pdf = func[i] / integral;
+    if (func) *pdf = func[i] / integral;
     *x = ((float)i + du) / (float)n;
     *idx = i;
 }
 FTN_DEV_NOINLINE Rgb light_Le_env(const DLight& L, V3 dir) {    /* infinite.rs:156-164 */
     V3 w = normalize(m4_vector(L.w2l, dir));
     V2 st(spherical_phi(w) * (1.0f / (2.0f * FTN_PI)), spherical_theta(w) * FTN_INV_PI);
+    if (L.cells) { int cx, cy; Rgb r; env_cell_of(L, st, &cx, &cy); if (env_cell_lookup(L, st, cx, cy, &r)) return r; }
     return env_lookup(L, st);
 }
 __device__ inline Rgb scene_env_Le(const DScene& S, V3 dir) {    /* scene/mod.rs:59-64: sum over all lights (non-infinite give 0) */
@@ -932,8 +961,10 @@ __device__ inline DLiSample light_sample_env(const DLight& L, const DSurfHit& re
     DLiSample s;
     float d1, pdf1, d0, pdf0; uint32_t vi, ui;
     dist1d_sample(L.marg_func, L.marg_cdf, L.marg_integral, L.nv, u.y, &d1, &pdf1, &vi, L.marg_coarse);
-    dist1d_sample(L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), L.cond_integral[vi], L.nu, u.x, &d0, &pdf0, &ui,
+    const float cint = L.cond_integral[vi];
+    dist1d_sample(L.cells ? nullptr : L.cond_func + (size_t)vi * L.nu, L.cond_cdf + (size_t)vi * (L.nu + 1), cint, L.nu, u.x, &d0, &pdf0, &ui,
                   L.cond_coarse ? L.cond_coarse + (size_t)vi * (((L.nu + 31u) >> 5) + 1u) : nullptr);
+    if (L.cells) pdf0 = env_cell_func(L, ui, vi) / cint;
     float map_pdf = pdf0 * pdf1;
     float theta = d1 * FTN_PI, phi = d0 * 2.0f * FTN_PI;
     float sth, cth, sph, cph;
@@ -942,7 +973,7 @@ __device__ inline DLiSample light_sample_env(const DLight& L, const DSurfHit& re
     s.pdf = (sth == 0.0f) ? 0.0f : map_pdf / (2.0f * FTN_PI * FTN_PI * sth);
     if (map_pdf == 0.0f) s.pdf = 0.0f;                                   /* reference: unimplemented!() */
     s.p1.p = ref.p + s.wi * (2.0f * L.world_radius); s.p1.p_err = V3(); s.p1.time = ref.time; s.p1.n = V3();
-    s.radiance = env_lookup(L, V2(d0, d1));
+    if (!(L.cells && env_cell_lookup(L, V2(d0, d1), (int)ui, (int)vi, &s.radiance))) s.radiance = env_lookup(L, V2(d0, d1));
     return s;
 }
 __device__ inline float light_pdf_env(const DLight& L, V3 wi) {                                  /* infinite.rs:142-154 */
@@ -953,7 +984,8 @@ __device__ inline float light_pdf_env(const DLight& L, V3 wi) {                 
     float px = phi * (1.0f / (2.0f * FTN_PI)), py = theta * FTN_INV_PI;
     long long iu = f2usize(px * (float)L.nu); if (iu > (long long)L.nu - 1) iu = (long long)L.nu - 1;
     long long iv = f2usize(py * (float)L.nv); if (iv > (long long)L.nv - 1) iv = (long long)L.nv - 1;
-    return (L.cond_func[(size_t)iv * L.nu + iu] / L.marg_integral) / (2.0f * FTN_PI * FTN_PI * sth);
+    const float fv = L.cells ? env_cell_func(L, (uint32_t)iu, (uint32_t)iv) : L.cond_func[(size_t)iv * L.nu + iu];
+    return (fv / L.marg_integral) / (2.0f * FTN_PI * FTN_PI * sth);
 }
 FTN_DEV_NOINLINE DLiSample light_sample(const DScene& S, const DLight& L, const DSurfHit& ref, V2 u) {
     DLiSample s;

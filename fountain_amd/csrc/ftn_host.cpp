@@ -1020,6 +1020,26 @@ static int upload_scene(const ftn_scene_desc* d, ftn_scene* sc) {
             if ((rc = b4.upload(cint.data(), cint.size()))) return rc;             /* marginal func == conditional integrals */
             if ((rc = b5.upload(mcdf.data(), mcdf.size()))) return rc;
             L.texels = b0.p; L.cond_func = b1.p; L.cond_cdf = b2.p; L.cond_integral = b3.p; L.marg_func = b4.p; L.marg_cdf = b5.p;
+            /* cell records (DLight::cells): square maps only -- compute_distribution's (height, width) swap makes the distribution's cell
+             * (u, v) the texel (u, v) only then.  FTN_ENV_CELLS=0: not built */
+            if (e.width == e.height && (uint64_t)e.width * e.height * 128u <= (2ull << 30) && !env_is("FTN_ENV_CELLS", 0)) {
+                const int w = (int)e.width, h = (int)e.height;
+                std::unique_ptr<float4[]> cells(new float4[8 * (size_t)w * h]);
+                parallel_for((size_t)h, [&](size_t y0, size_t y1) { for (size_t cy = y0; cy < y1; cy++) for (int cx = 0; cx < w; cx++) {
+                    float* c = reinterpret_cast<float*>(&cells[8 * (cy * (size_t)w + (size_t)cx)]);
+                    for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+                        const int sx = ((cx + dx) % w + w) % w, sy = (((int)cy + dy) % h + h) % h;        /* env_texel's wrap */
+                        const float4 t = tex4[(size_t)sy * w + sx];
+                        float* o = c + 3 * ((dy + 1) * 3 + dx + 1);
+                        o[0] = t.x; o[1] = t.y; o[2] = t.z;
+                    }
+                    c[27] = img[(size_t)cx + cy * (size_t)width];
+                    c[28] = c[29] = c[30] = c[31] = 0.0f;
+                } });
+                DevBuf<float4> bc;
+                if ((rc = bc.upload(cells.get(), 8 * (size_t)w * h))) return rc;
+                L.cells = bc.p; sc->misc4.push_back(bc);
+            }
             {   /* every 32nd CDF entry (DLight::cond_coarse / marg_coarse); only for CDFs that really are non-decreasing */
                 bool monotone = true;
                 auto check = [&](const float* c, uint32_t n) { for (uint32_t k = 0; k < n; k++) if (!(c[k] <= c[k + 1])) monotone = false; };

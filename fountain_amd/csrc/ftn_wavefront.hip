@@ -1515,6 +1515,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     if (dl_mode) { st->W.dlA = (float4*)st->dl_mem[0]; st->W.dlB = (float4*)st->dl_mem[1]; st->W.whT = (float4*)st->dl_mem[2]; st->W.dfd = (float4*)st->dl_mem[7]; }
     WfBuffers W = st->W;
     if (dl_mode) { W.sh = (float4*)st->dl_mem[3]; W.occluded = (unsigned char*)st->dl_mem[4]; W.q_shadow = (uint32_t*)st->dl_mem[5]; W.q_exc_any = (uint32_t*)st->dl_mem[6]; }
+    if (!knob("FTN_ENV_CELLS_USE", 1)) P.S.env0.cells = nullptr;      /* (A/B in one process: the environment-only kernels read the light from the kernel arguments) */
     const bool spheres = P.S.n_spheres != 0;
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
