@@ -743,10 +743,11 @@ def test_furnace_path_no_rr_on_the_wavefront_pipeline(gpu, orc_det):
 
 
 @pytest.mark.parametrize("pipeline,kernels", [(MEGA, "counting"), (WAVE, "counting"), (WAVE, "production")])
-@pytest.mark.parametrize("shape", [(6, 3), (3, 6), (8, 4), (5, 7), (1, 4), (12, 1), (100, 37)])
+@pytest.mark.parametrize("shape", [(6, 3), (3, 6), (8, 4), (5, 7), (1, 4), (12, 1), (100, 37), (1, 1), (2, 2), (7, 7), (16, 16), (33, 33)])
 def test_environment_maps_of_any_size(gpu, orc_det, shape, pipeline, kernels):
     """non-square and non-power-of-two environment maps (infinite.rs:63-77: only pyramid level 0 is ever read; the (height, width) name
-    swap of compute_distribution reproduced as written): importance sampling, pdf and Le bit-equal to the oracle's"""
+    swap of compute_distribution reproduced as written): importance sampling, pdf and Le bit-equal to the oracle's.  Square maps read
+    the cell records (DLight::cells: a cell's 3 x 3 texel neighbourhood, wrapped at the borders, and its function value in one line)"""
     from test_oracle_integration import _env_scene
     rng = np.random.default_rng(shape[0] * 131 + shape[1])
     tex = (rng.random(shape + (3,)) ** 3 * 2).astype(np.float32)
@@ -754,6 +755,27 @@ def test_environment_maps_of_any_size(gpu, orc_det, shape, pipeline, kernels):
     (rgb, px, st), (rgbo, pxo, sto) = render_pair(gpu, orc_det, lambda be: _env_scene(be, tex), PathIntegrator.new(4, 1.0), RandomSampler(4, 0, indexed=True), pipeline, kernels)
     assert_film_equal(px, pxo, st["spill_samples"], "env map %dx%d" % shape)
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and rgb.max() > 0.5
+
+
+def test_environment_cell_records_change_nothing(gpu, monkeypatch):
+    """the cell records of a square environment map (built at scene creation; FTN_ENV_CELLS=0: not built; FTN_ENV_CELLS_USE=0: built but the
+    environment-only kernels read the plain tables): same film, same counts, on both pipelines"""
+    films = {}
+    for build, use in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("FTN_ENV_CELLS", build); monkeypatch.setenv("FTN_ENV_CELLS_USE", use)
+        sc, cam, res = _env_only_scene(gpu)
+        if build == "1": big = sc.info()["lights_bytes"]
+        else: assert sc.info()["lights_bytes"] <= big - 16 * 16 * 128
+        for pl in (WAVE, MEGA):
+            f = Film(gpu, res)
+            st = SamplerIntegrator(cam, PathIntegrator.new(6, 1.0)).render_parallel(sc, f, RandomSampler(4, 3, indexed=True), pipeline=pl)
+            films[(build, use, pl)] = (f.pixels, st["rays_closest"], st["rays_any"])
+    ref = films[("1", "1", WAVE)]
+    for k, v in films.items():
+        assert v[1] == ref[1] and v[2] == ref[2], k
+        diff = (bits(v[0]) != bits(ref[0])).any(axis=-1).sum()
+        assert diff == 0 or k[2] == MEGA, k                       # (the two pipelines may differ in the last bit of spill pixels only)
+        assert np.allclose(v[0], ref[0], rtol=2e-6, atol=1e-7), k
 
 
 # ------------------------------------------------------------------ DirectLightingIntegrator / WhittedIntegrator through the wavefront queues (SURVEY 8(f).3)
