@@ -1201,21 +1201,27 @@ static int trace4_prepare(WavefrontState* st, const DScene& S) {
 /* count: 0 = production kernels, 1 = counting build of the REFERENCE walk (node / primitive tallies equal the oracle's), 2 = counting
  * build of the production kernels (what bench.py's byte model uses).  n_queue: upper bound of the queue's length (sizes the grid). */
 static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, unsigned grid, size_t lds, hipStream_t stream, const RenderParams& P, const WfBuffers& W,
-                         const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays) {
+                         const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head, uint32_t max_rays, bool camera_rays = false) {
     if (st->t4_on && count != 1) {     /* four-box records */
         const Trace4Plan& T = st->t4;
         const bool oct = any && st->t8_on;
         const unsigned g = std::min<unsigned>(oct ? T.grid_oct : (any ? T.grid_any : T.grid_closest), std::max<unsigned>(1u, (max_rays + 255u) / 256u));
         uint32_t chunk4 = knob("FTN_TRACE_CHUNK", 128);
         while (chunk4 > 64u && (uint64_t)chunk4 * g * 4u * 4u > (uint64_t)max_rays) chunk4 >>= 1;
-        /* measured optima on the config-5 scene (profiles/r02_*, r03): lanes re-armed once 24 (closest, eight-box any-hit) / 32 (four-box any-hit)
-         * are idle, leaf steps run once 16 lanes hold a leaf, 2 / 4 record steps per control round */
+        /* measured optima on the config-5 scene (profiles/r02_*, r03): lanes re-armed once 32 (closest, four-box any-hit) / 24 (eight-box any-hit)
+         * are idle, leaf steps run once 16 lanes hold a leaf, 2 / 4 record steps per control round.
+         * The camera rays' launch is the exception: its 64 rays per wave are four pixels' samples and walk the same records, so a wave that
+         * re-arms only when ALL of its lanes are done keeps them in lockstep (every load of a step hits the same lines, the ray setup runs once
+         * per 64 rays at full width): 46.2 -> 37.1 ms per step with FTN_T4_REFILL0 = 64, leaf steps as soon as 2 lanes hold a leaf, 3 record
+         * steps per round (profiles/r03/n_*); at 60 instead of 64 the gain is gone, the incoherent launches lose 50 % with it, and so does a
+         * pass of ONE sample per pixel (64 pixels per wave: +2 %), which keeps the common parameters */
         if (oct) launch_trace4(T4K_ANY_OCT, count == 2, false, g, T.lds_oct, T.entries_oct, st->t4_spill_a, stream, P.S, W, queue, count_ptr, head, P.stats,
                                knob("FTN_T8_REFILL", 24), knob("FTN_T8_LEAF_BATCH", 16), chunk4, knob("FTN_T8_BURST", 2), knob("FTN_T8_POLICY", 1), T.spill_oct);
         else launch_trace4(any ? T4K_ANY : T4K_CLOSEST, count == 2, spheres, g, any ? T.lds_any : T.lds_closest, any ? T.entries_any : T.entries_closest, any ? st->t4_spill_a : st->t4_spill_c, stream, P.S, W,
                       queue, count_ptr, head, P.stats,
-                      any ? knob("FTN_T4_ANY_REFILL", 32) : knob("FTN_T4_REFILL", 24), any ? knob("FTN_T4_ANY_LEAF_BATCH", 16) : knob("FTN_T4_LEAF_BATCH", 16), chunk4,
-                      any ? knob("FTN_T4_ANY_BURST", 4) : knob("FTN_T4_BURST", 2), knob("FTN_T4_ANY_POLICY", 1), any ? T.spill_any : T.spill_closest);
+                      any ? knob("FTN_T4_ANY_REFILL", 32) : (camera_rays ? knob("FTN_T4_REFILL0", 64) : knob("FTN_T4_REFILL", 32)),
+                      any ? knob("FTN_T4_ANY_LEAF_BATCH", 16) : (camera_rays ? knob("FTN_T4_LEAF_BATCH0", 2) : knob("FTN_T4_LEAF_BATCH", 16)), chunk4,
+                      any ? knob("FTN_T4_ANY_BURST", 4) : (camera_rays ? knob("FTN_T4_BURST0", 3) : knob("FTN_T4_BURST", 2)), knob("FTN_T4_ANY_POLICY", 1), any ? T.spill_any : T.spill_closest);
         /* the rays it handed back (a zero direction component: ftn_trace4.hip, point 5) take the reference-order kernel.  The queue is
          * nearly always empty and the persistent workgroups leave at once; its rays are already in the statistics (stats = NULL) */
         const unsigned ge = std::min<unsigned>(grid, (unsigned)st->n_cu);
@@ -1593,7 +1599,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 W.drain_at = 1;           /* the first wave (waiting for 10-75 % of the waves to be dry measured the same) */
             }
             { const int e = span_begin(stream);
-              launch_trace(st, false, count_mode, spheres, tg, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths);
+              launch_trace(st, false, count_mode, spheres, tg, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths,
+                           it == 0 && W.samples >= 4u /* a wave's 64 rays are at most 16 pixels' samples: the lockstep parameters (launch_trace) */);
               span_end(e, 0, stream); }
             if (gated) WF_TRY(hipStreamWriteValue32(stream, st->drain_sig, W.drain_seq, 0));
             trace_launches++;
