@@ -65,7 +65,12 @@ __global__ void __launch_bounds__(256) k_wf_generate(RenderParams P, WfBuffers W
         /* queue order = path order: tile, pixel, sample.  A wave of the first trace (and of the first shading pass, and of the shadow
          * rays it emits) covers a few pixels instead of 64, each XCD's slice of the queue is a part of the image rather than one whole
          * sample of it, and the path state is still read in order. */
-        const uint32_t pix = tile.valid_off + (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
+        uint32_t local = (uint32_t)(py - tile.y0) * (uint32_t)(tile.x1 - tile.x0) + (uint32_t)(px - tile.x0);
+        if (W.gen_blocks && tile.x1 - tile.x0 == 16 && tile.y1 - tile.y0 == 16) {          /* Morton order inside a full tile: x bits at even, y bits at odd positions */
+            const uint32_t x = slot & 15u, y = (slot >> 4) & 15u;
+            local = (x & 1u) | ((y & 1u) << 1) | ((x & 2u) << 1) | ((y & 2u) << 2) | ((x & 4u) << 2) | ((y & 4u) << 3) | ((x & 8u) << 3) | ((y & 8u) << 4);
+        }
+        const uint32_t pix = tile.valid_off + local;
         const uint32_t qi = pix * W.samples + s;
         W.q_active[0][qi] = i | (P.max_depth == 0 ? WF_Q_DEPTH : 0u);
         W.q_closest[qi] = i;
@@ -1216,7 +1221,7 @@ static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, 
          * steps per round (profiles/r03/n_*); at 60 instead of 64 the gain is gone, the incoherent launches lose 50 % with it, and so does a
          * pass of ONE sample per pixel (64 pixels per wave: +2 %), which keeps the common parameters */
         if (oct) launch_trace4(T4K_ANY_OCT, count == 2, false, g, T.lds_oct, T.entries_oct, st->t4_spill_a, stream, P.S, W, queue, count_ptr, head, P.stats,
-                               knob("FTN_T8_REFILL", 24), knob("FTN_T8_LEAF_BATCH", 16), chunk4, knob("FTN_T8_BURST", 2), knob("FTN_T8_POLICY", 1), T.spill_oct);
+                               camera_rays ? knob("FTN_T8_REFILL1", 16) : knob("FTN_T8_REFILL", 24), camera_rays ? knob("FTN_T8_LEAF_BATCH1", 16) : knob("FTN_T8_LEAF_BATCH", 16), chunk4, knob("FTN_T8_BURST", 2), knob("FTN_T8_POLICY", 1), T.spill_oct);
         else launch_trace4(any ? T4K_ANY : T4K_CLOSEST, count == 2, spheres, g, any ? T.lds_any : T.lds_closest, any ? T.entries_any : T.entries_closest, any ? st->t4_spill_a : st->t4_spill_c, stream, P.S, W,
                       queue, count_ptr, head, P.stats,
                       any ? knob("FTN_T4_ANY_REFILL", 32) : (camera_rays ? knob("FTN_T4_REFILL0", 64) : knob("FTN_T4_REFILL", 32)),
@@ -1394,6 +1399,7 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
     WfBuffers W = st->W;
     W.serial = 1; W.ser_cursor = (uint2*)st->ser_mem[0]; W.ser_pfilm = (float2*)st->ser_mem[1]; W.ser_retired = (unsigned char*)st->ser_mem[2]; W.dfd = (float4*)st->ser_mem[3];
     W.n_slots = 0; W.samples = 1; W.n_paths = n_tiles; W.first_sample = 0; W.seg_cap = (uint32_t)st->cap_paths; W.valid_per_sample = 0;
+    W.gen_blocks = 0;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     const bool spheres = P.S.n_spheres != 0;
@@ -1526,6 +1532,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
+    W.gen_blocks = knob("FTN_GEN_BLOCKS", 0);
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
@@ -1612,7 +1619,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                 const unsigned sg = std::min<unsigned>(trace_grid_max, (2 * W.n_paths + 255) / 256);
                 hipStream_t as = beside ? st->side : stream;
                 const int e = span_begin(as);
-                launch_trace(st, true, count_mode, spheres, sg, lds, as, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths);
+                launch_trace(st, true, count_mode, spheres, sg, lds, as, P, W, q_sh, &W.counters[CTR(3)], &W.counters[CTR(24)], 2 * W.n_paths, it == 1 && W.samples >= 4u);
                 span_end(e, 1, as);
                 if (beside) WF_TRY(hipEventRecord(st->ev_side, st->side));
             }

@@ -51,6 +51,8 @@ struct WfBuffers {
     uint2* ser_cursor;          /* per tile: {pixel index inside the tile (row-major over its extent), sample index} of the sample in flight */
     float2* ser_pfilm;          /* ... and its film position */
     unsigned char* ser_retired;
+    uint32_t gen_blocks;        /* 1: k_wf_generate queues the pixels of a full 16 x 16 tile in 2 x 2 blocks (Morton order) instead of rows: the 64 rays of a
+                                 * wave of the first trace are then a 2 x 2 pixel block at 16 spp, not a 4 x 1 strip.  Queue ORDER only: no result depends on it */
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
 };
 
