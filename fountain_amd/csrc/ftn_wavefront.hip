@@ -1532,7 +1532,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
-    W.gen_blocks = knob("FTN_GEN_BLOCKS", 0);
+    W.gen_blocks = knob("FTN_GEN_BLOCKS", 1);      /* camera rays of a full tile queued in 2 x 2 pixel blocks: first closest-hit launch 37.3 -> 36.6 ms */
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
     const unsigned trace_grid_max = (unsigned)st->n_cu * blocks_per_cu;
