@@ -757,6 +757,24 @@ def test_environment_maps_of_any_size(gpu, orc_det, shape, pipeline, kernels):
     assert st["rays_closest"] == sto["rays_closest"] and st["rays_any"] == sto["rays_any"] and rgb.max() > 0.5
 
 
+def test_launch_schedules_change_nothing(gpu, monkeypatch):
+    """the control parameters of the traversal launches -- the camera rays' lockstep launch (a wave re-arms only when all 64 lanes are done),
+    the 2 x 2 pixel-block queue order of full tiles, re-arm thresholds, leaf batches -- decide WHEN a ray is walked, never what it hits:
+    same film bit for bit, same counts"""
+    sc, cam, res = _env_only_scene(gpu, res=(128, 96))
+    si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+    out = {}
+    for name, env in (("default", {}), ("no lockstep", {"FTN_T4_REFILL0": "24", "FTN_T4_LEAF_BATCH0": "16", "FTN_T4_BURST0": "2"}), ("row order", {"FTN_GEN_BLOCKS": "0"}),
+                      ("odd", {"FTN_T4_REFILL": "7", "FTN_T8_REFILL1": "60", "FTN_T4_LEAF_BATCH0": "64", "FTN_T4_BURST0": "1", "FTN_T8_LEAF_BATCH1": "3"})):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        f = Film(gpu, res)
+        st = si.render_parallel(sc, f, RandomSampler(8, 1, indexed=True), pipeline=WAVE)
+        out[name] = (f.pixels, st["rays_closest"], st["rays_any"])
+        for k in env: monkeypatch.delenv(k)
+    for name, v in out.items():
+        assert np.array_equal(bits(v[0]), bits(out["default"][0])) and v[1:] == out["default"][1:], name
+
+
 def test_environment_cell_records_change_nothing(gpu, monkeypatch):
     """the cell records of a square environment map (built at scene creation; FTN_ENV_CELLS=0: not built; FTN_ENV_CELLS_USE=0: built but the
     environment-only kernels read the plain tables): same film, same counts, on both pipelines"""
