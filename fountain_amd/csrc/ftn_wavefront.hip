@@ -1218,8 +1218,9 @@ static void launch_trace(WavefrontState* st, bool any, int count, bool spheres, 
          * The camera rays' launch is the exception: its 64 rays per wave are four pixels' samples and walk the same records, so a wave that
          * re-arms only when ALL of its lanes are done keeps them in lockstep (every load of a step hits the same lines, the ray setup runs once
          * per 64 rays at full width): 46.2 -> 37.1 ms per step with FTN_T4_REFILL0 = 64, leaf steps as soon as 2 lanes hold a leaf, 3 record
-         * steps per round (profiles/r03/n_*); at 60 instead of 64 the gain is gone, the incoherent launches lose 50 % with it, and so does a
-         * pass of ONE sample per pixel (64 pixels per wave: +2 %), which keeps the common parameters */
+         * steps per round (profiles/r03/n_*); at 60 instead of 64 the gain is gone, and the incoherent launches lose 50 % with it.  With
+         * the pixels of a tile queued in 2 x 2 blocks (k_wf_generate) a pass of ONE sample per pixel gains too (a wave = an 8 x 8 block:
+         * 25.5 -> 24.9 ms at 4096^2; with rows of 16 pixels it lost 2 %) */
         if (oct) launch_trace4(T4K_ANY_OCT, count == 2, false, g, T.lds_oct, T.entries_oct, st->t4_spill_a, stream, P.S, W, queue, count_ptr, head, P.stats,
                                camera_rays ? knob("FTN_T8_REFILL1", 16) : knob("FTN_T8_REFILL", 24), camera_rays ? knob("FTN_T8_LEAF_BATCH1", 16) : knob("FTN_T8_LEAF_BATCH", 16), chunk4, knob("FTN_T8_BURST", 2), knob("FTN_T8_POLICY", 1), T.spill_oct);
         else launch_trace4(any ? T4K_ANY : T4K_CLOSEST, count == 2, spheres, g, any ? T.lds_any : T.lds_closest, any ? T.entries_any : T.entries_closest, any ? st->t4_spill_a : st->t4_spill_c, stream, P.S, W,
@@ -1607,7 +1608,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
             }
             { const int e = span_begin(stream);
               launch_trace(st, false, count_mode, spheres, tg, lds, stream, P, W, q_cl, &W.counters[CTR(2)], &W.counters[CTR(16)], 2 * W.n_paths,
-                           it == 0 && W.samples >= 4u /* a wave's 64 rays are at most 16 pixels' samples: the lockstep parameters (launch_trace) */);
+                           it == 0 && W.samples >= knob("FTN_T4_LOCKSTEP_MIN_SPP", 1) /* a wave's 64 rays are at most 16 pixels' samples: the lockstep parameters (launch_trace) */);
               span_end(e, 0, stream); }
             if (gated) WF_TRY(hipStreamWriteValue32(stream, st->drain_sig, W.drain_seq, 0));
             trace_launches++;

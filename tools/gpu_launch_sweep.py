@@ -17,8 +17,11 @@ dev = torch.zeros((film.height, film.width, 4), dtype=torch.float32, device="cud
 stream = torch.cuda.current_stream()
 
 
+SPP = int(os.environ.get("SWEEP_SPP", "16"))
+
+
 def step(i):
-    smp = RandomSampler(4096, 0, indexed=True, first_sample=(i * 16) % 4096, sample_count=16)
+    smp = RandomSampler(4096, 0, indexed=True, first_sample=(i * SPP) % 4096, sample_count=SPP)
     return si.render_device(sc, film, smp, dev.data_ptr(), stream.cuda_stream, pipeline=A.FTN_PIPELINE_WAVEFRONT)
 
 
