@@ -1037,6 +1037,10 @@ struct Rng {
         return (float)((uint32_t)(result >> 32) >> 8) * (1.0f / 16777216.0f);
     }
     __device__ V2 next2() { float a = next(); float b = next(); return V2(a, b); }
+    /* the state after n further draws (the update of next() without its output) */
+    __device__ void skip(uint32_t n) {
+        for (uint32_t i = 0; i < n; i++) { const uint64_t t = s1 << 17; s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = (s3 << 45) | (s3 >> 19); }
+    }
 };
 __device__ inline uint64_t indexed_key(uint64_t seed, int px, int py, uint32_t sample) {
     return (seed * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)(uint32_t)py << 40) ^ ((uint64_t)(uint32_t)px << 20) ^ (uint64_t)sample;

@@ -520,7 +520,13 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                         const DTile tile = P.tiles[slot >> 8];
                         rng.seed(indexed_key(P.seed, tile.x0 + (int)(slot & 15u), tile.y0 + (int)((slot >> 4) & 15u), W.first_sample + sidx));
                         (void)rng.next2(); (void)rng.next2(); (void)rng.next();
+                    } else if (W.rng_replay) {   /* the same stream, re-created: seed of the sample's key, then the draws the path has made so far */
+                        const uint32_t slot = p / W.samples, sidx = p % W.samples;
+                        const DTile tile = P.tiles[slot >> 8];
+                        rng.seed(indexed_key(P.seed, tile.x0 + (int)(slot & 15u), tile.y0 + (int)((slot >> 4) & 15u), W.first_sample + sidx));
+                        rng.skip(ps >> PS_DRAWS_SHIFT);
                     } else { ulonglong2 a = W.rng01[p], b = W.rng23[p]; rng.s0 = a.x; rng.s1 = a.y; rng.s2 = b.x; rng.s3 = b.y; }
+                    uint32_t n_draws = first ? 5u : (ps >> PS_DRAWS_SHIFT);
                     const int mat = si.mat;
                     if (MT == -2 || mat < 0) {
                         DRay nr = spawn_ray(si.hit, ray0.d);                       /* null bsdf: path.rs:77-81 */
@@ -556,6 +562,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                 const uint32_t nl = S.n_lights;
                                 const uint32_t ln = (uint32_t)f2usize(fmin_(rng.next() * (float)nl, (float)(nl - 1)));
                                 const V2 ul = rng.next2(), us = rng.next2();
+                                n_draws += 5u;
                                 const DLight& Lt = ENV ? S.env0 : S.lights[ln];
                                 const uint32_t flags = T_ALL & ~T_SPECULAR;
                                 const bool delta = !ENV && (Lt.kind == LK_POINT || Lt.kind == LK_DISTANT);
@@ -600,6 +607,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                             /* sample the BSDF for the next direction (path.rs:67-76) */
                             DScatter bs;
                             const V2 u = rng.next2();
+                            n_draws += 2u;
                             const bool ok = bsdf_sample(B, -ray0.d, u, T_ALL, &bs);
                             if (ok && !bs.f.is_black()) {
                                 beta = beta * (bs.f * abs_dot(bs.wi, si.shading_n) / bs.pdf);
@@ -608,6 +616,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                 /* Russian roulette (path.rs:84-91) */
                                 if (beta.max_component() < P.rr_threshold && bounces > 3) {
                                     float q = fmax_(0.05f, 1.0f - beta.max_component());
+                                    n_draws += 1u;
                                     if (rng.next() < q) alive = false; else beta = beta / (1.0f - q);
                                 }
                                 if (alive) {
@@ -617,7 +626,8 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                             } else alive = false;
                         }
                     }
-                    if (alive || W.serial) { W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3); }      /* (an ended path draws nothing more; the tile-serial stream goes on behind it) */
+                    if (W.rng_replay) ps = (ps & ((1u << PS_DRAWS_SHIFT) - 1u)) | (n_draws << PS_DRAWS_SHIFT);
+                    else if (alive || W.serial) { W.rng01[p] = make_ulonglong2(rng.s0, rng.s1); W.rng23[p] = make_ulonglong2(rng.s2, rng.s3); }      /* (an ended path draws nothing more; the tile-serial stream goes on behind it) */
                 }
                 ps = (ps & ~(PS_BOUNCE_MASK | PS_ALIVE)) | (bounces & PS_BOUNCE_MASK) | (alive ? PS_ALIVE : 0u);
                 push_active = alive || (ps & PS_DIRECT);        /* finished paths with a pending direct term come back once */
@@ -1400,7 +1410,7 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
     WfBuffers W = st->W;
     W.serial = 1; W.ser_cursor = (uint2*)st->ser_mem[0]; W.ser_pfilm = (float2*)st->ser_mem[1]; W.ser_retired = (unsigned char*)st->ser_mem[2]; W.dfd = (float4*)st->ser_mem[3];
     W.n_slots = 0; W.samples = 1; W.n_paths = n_tiles; W.first_sample = 0; W.seg_cap = (uint32_t)st->cap_paths; W.valid_per_sample = 0;
-    W.gen_blocks = 0;
+    W.gen_blocks = 0; W.rng_replay = 0;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     const bool spheres = P.S.n_spheres != 0;
@@ -1533,6 +1543,8 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     uint32_t valid = 0; for (const DTile& t : tiles) valid += (uint32_t)((t.x1 - t.x0) * (t.y1 - t.y0));
     W.valid_per_sample = valid;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
+    /* the path integrator's streams replayed from the sample key instead of carried (WfBuffers::rng_replay): when the draw count fits its 9 bits */
+    W.rng_replay = (!dl_mode && 5u + 8u * ((uint32_t)P.max_depth + 1u) <= 511u && knob("FTN_RNG_REPLAY", 1)) ? 1u : 0u;      /* shading 101.7 -> 96.9 ms per step */
     W.gen_blocks = knob("FTN_GEN_BLOCKS", 1);      /* camera rays of a full tile queued in 2 x 2 pixel blocks: first closest-hit launch 37.3 -> 36.6 ms */
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));

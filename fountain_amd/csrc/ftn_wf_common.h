@@ -11,6 +11,7 @@ namespace ftn {
 
 /* the bounce count takes 16 bits: PathIntegrator::max_depth is a u16 in the reference (path.rs:14), and ftn_render_device refuses more */
 enum : uint32_t { PS_BOUNCE_MASK = 0xffffu, PS_SPECULAR = 1u << 16, PS_ALIVE = 1u << 17, PS_DIRECT = 1u << 18, PS_SHADOW = 1u << 19, PS_MIS = 1u << 20, PS_DELTA = 1u << 21, PS_MIS_ANY = 1u << 22 /* the MIS ray went through the any-hit kernel */ };
+#define PS_DRAWS_SHIFT 23          /* rng_replay: draws made so far, 9 bits (wavefront_render enables it only when 5 + 8 * (max_depth + 1) fits) */
 #define WF_MIS_BIT 0x80000000u
 
 struct WfBuffers {
@@ -51,6 +52,8 @@ struct WfBuffers {
     uint2* ser_cursor;          /* per tile: {pixel index inside the tile (row-major over its extent), sample index} of the sample in flight */
     float2* ser_pfilm;          /* ... and its film position */
     unsigned char* ser_retired;
+    uint32_t rng_replay;        /* 1: a path's Xoshiro stream is not carried in rng01 / rng23 but re-created from its sample key and the number of draws made so far
+                                 * (bits 23-31 of the path-state word: PS_DRAWS_SHIFT): 64 bytes less per shading event, ~16 instructions per replayed draw */
     uint32_t gen_blocks;        /* 1: k_wf_generate queues the pixels of a full 16 x 16 tile in 2 x 2 blocks (Morton order) instead of rows: the 64 rays of a
                                  * wave of the first trace are then a 2 x 2 pixel block at 16 spp, not a 4 x 1 strip.  Queue ORDER only: no result depends on it */
     uint32_t mis_any;           /* 1: MIS rays toward an infinite light only need hit / miss -> any-hit kernel (off in the counting build, whose node tallies must equal the reference's closest-hit walk) */
