@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
         if (have) {
             p = W.q_sorted[sorted_idx];
             float4 bq = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(PS_ALIVE)), lq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       /* a fresh path (k_wf_generate) */
-            if (!first) { bq = W.beta[p]; lq = W.rad[p]; }
+            if (!first) { if (W.br) { bq = W.br[2 * (size_t)p]; lq = W.br[2 * (size_t)p + 1]; } else { bq = W.beta[p]; lq = W.rad[p]; } }
             Rgb beta(bq.x, bq.y, bq.z), L(lq.x, lq.y, lq.z);
             uint32_t ps = __float_as_uint(bq.w);
             /* ---- finish the previous bounce's estimate_direct (integrator/mod.rs:330-392) */
@@ -631,8 +631,13 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                 }
                 ps = (ps & ~(PS_BOUNCE_MASK | PS_ALIVE)) | (bounces & PS_BOUNCE_MASK) | (alive ? PS_ALIVE : 0u);
                 push_active = alive || (ps & PS_DIRECT);        /* finished paths with a pending direct term come back once */
-                if (push_active) W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));        /* (a retired path's throughput is never read again) */
-                W.rad[p] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word));
+                if (W.br) {
+                    if (push_active) { W.br[2 * (size_t)p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps)); W.br[2 * (size_t)p + 1] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word)); }
+                    else W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);
+                } else {
+                    if (push_active) W.beta[p] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(ps));        /* (a retired path's throughput is never read again) */
+                    W.rad[p] = make_float4(L.r, L.g, L.b, __uint_as_float(light_word));
+                }
                 active_entry = p | (alive ? (bounces >= P.max_depth ? WF_Q_DEPTH : 0u) : WF_Q_FIN);
             }
             if (W.serial && !push_active) W.ser_retired[p] = 1;      /* nothing pending: k_wf_serial_advance takes it from here */
@@ -1114,6 +1119,7 @@ struct WavefrontState {
     size_t cap_paths = 0;
     void* mem[40]; int n_mem = 0;
     WfBuffers W;
+    float4* br = nullptr;          /* WfBuffers::br */
     hipEvent_t ev[64]; int n_ev = 0;
     hipStream_t side = nullptr; hipEvent_t ev_ready = nullptr, ev_side = nullptr;     /* the any-hit launches run beside the closest-hit ones */
     uint32_t* drain_sig = nullptr; uint32_t drain_seq = 0;                              /* signal memory for hipStreamWaitValue32 (NULL: not supported) */
@@ -1159,7 +1165,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32))) return rc;
+        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32)) || (rc = wf_alloc(st, &st->br, 2 * n))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -1410,7 +1416,7 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
     WfBuffers W = st->W;
     W.serial = 1; W.ser_cursor = (uint2*)st->ser_mem[0]; W.ser_pfilm = (float2*)st->ser_mem[1]; W.ser_retired = (unsigned char*)st->ser_mem[2]; W.dfd = (float4*)st->ser_mem[3];
     W.n_slots = 0; W.samples = 1; W.n_paths = n_tiles; W.first_sample = 0; W.seg_cap = (uint32_t)st->cap_paths; W.valid_per_sample = 0;
-    W.gen_blocks = 0; W.rng_replay = 0;
+    W.gen_blocks = 0; W.rng_replay = 0; W.br = nullptr;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     const bool spheres = P.S.n_spheres != 0;
@@ -1545,6 +1551,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     /* the path integrator's streams replayed from the sample key instead of carried (WfBuffers::rng_replay): when the draw count fits its 9 bits */
     W.rng_replay = (!dl_mode && 5u + 8u * ((uint32_t)P.max_depth + 1u) <= 511u && knob("FTN_RNG_REPLAY", 1)) ? 1u : 0u;      /* shading 101.7 -> 96.9 ms per step */
+    W.br = (!dl_mode && knob("FTN_WF_BR", 1)) ? st->br : nullptr;
     W.gen_blocks = knob("FTN_GEN_BLOCKS", 1);      /* camera rays of a full tile queued in 2 x 2 pixel blocks: first closest-hit launch 37.3 -> 36.6 ms */
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));

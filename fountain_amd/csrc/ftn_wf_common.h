@@ -27,6 +27,8 @@ struct WfBuffers {
     unsigned char* occluded;    /* per path */
     float4 *beta;               /* beta.xyz, bits(pstate) */
     float4 *rad;                /* L.xyz, bits(light index of the pending direct term) */
+    float4* br;                 /* path integrator (NULL: not used): throughput and running radiance of a path side by side, br[2 p] = beta's record, br[2 p + 1] =
+                                 * rad's -- the two are always read and written together, one scattered access instead of two; rad[] then only receives FINAL radiance */
     ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
     uint32_t *q_active[2], *q_closest, *q_shadow;   /* active-queue entries carry WF_Q_FIN / WF_Q_DEPTH in their top bits */
