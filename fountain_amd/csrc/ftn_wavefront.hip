@@ -460,7 +460,8 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
             uint32_t ps = __float_as_uint(bq.w);
             /* ---- finish the previous bounce's estimate_direct (integrator/mod.rs:330-392) */
             if (ps & PS_DIRECT) {
-                const float4 q0 = W.pend0[p], q1 = W.pend1[p], q2 = W.pend2[p];
+                float4 q0, q1, q2;
+                if (W.pd) { const float4* Q = W.pd + 4 * (size_t)p; q0 = Q[0]; q1 = Q[1]; q2 = Q[2]; } else { q0 = W.pend0[p]; q1 = W.pend1[p]; q2 = W.pend2[p]; }
                 Rgb radiance(0.0f);
                 if ((ps & PS_SHADOW) && !W.occluded[p]) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
                 if (ps & PS_MIS_ANY) {                           /* infinite light: the BSDF-sampled ray either escapes to it or contributes nothing (mod.rs:367-384) */
@@ -600,9 +601,14 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                         }
                                     }
                                 }
-                                W.pend0[p] = make_float4(ld.r, ld.g, ld.b, mis_w);
-                                W.pend1[p] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf);
-                                W.pend2[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                                if (W.pd) {
+                                    float4* Q = W.pd + 4 * (size_t)p;
+                                    Q[0] = make_float4(ld.r, ld.g, ld.b, mis_w); Q[1] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf); Q[2] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                                } else {
+                                    W.pend0[p] = make_float4(ld.r, ld.g, ld.b, mis_w);
+                                    W.pend1[p] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf);
+                                    W.pend2[p] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                                }
                             }
                             /* sample the BSDF for the next direction (path.rs:67-76) */
                             DScatter bs;
@@ -1119,7 +1125,7 @@ struct WavefrontState {
     size_t cap_paths = 0;
     void* mem[40]; int n_mem = 0;
     WfBuffers W;
-    float4* br = nullptr;          /* WfBuffers::br */
+    float4* br = nullptr; float4* pd = nullptr;          /* WfBuffers::br, WfBuffers::pd */
     hipEvent_t ev[64]; int n_ev = 0;
     hipStream_t side = nullptr; hipEvent_t ev_ready = nullptr, ev_side = nullptr;     /* the any-hit launches run beside the closest-hit ones */
     uint32_t* drain_sig = nullptr; uint32_t drain_seq = 0;                              /* signal memory for hipStreamWaitValue32 (NULL: not supported) */
@@ -1165,7 +1171,7 @@ static int wf_reserve(WavefrontState* st, size_t n) {
         (rc = wf_alloc(st, &W.sh, 2 * n)) || (rc = wf_alloc(st, &W.occluded, 2 * n)) || (rc = wf_alloc(st, &W.beta, n)) || (rc = wf_alloc(st, &W.rad, n)) ||
         (rc = wf_alloc(st, &W.rng01, n)) || (rc = wf_alloc(st, &W.rng23, n)) || (rc = wf_alloc(st, &W.pend0, n)) || (rc = wf_alloc(st, &W.pend1, n)) || (rc = wf_alloc(st, &W.pend2, n)) ||
         (rc = wf_alloc(st, &W.q_active[0], n)) || (rc = wf_alloc(st, &W.q_active[1], n)) || (rc = wf_alloc(st, &W.q_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_shadow, 2 * n)) || (rc = wf_alloc(st, &W.q_sorted, 8 * n)) || (rc = wf_alloc(st, &W.cls, 8 * 32)) ||
-        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32)) || (rc = wf_alloc(st, &st->br, 2 * n))) return rc;
+        (rc = wf_alloc(st, &W.q_exc_closest, 2 * n)) || (rc = wf_alloc(st, &W.q_exc_any, 2 * n)) || (rc = wf_alloc(st, &W.counters, 64 * 32)) || (rc = wf_alloc(st, &st->br, 2 * n)) || (rc = wf_alloc(st, &st->pd, 4 * n))) return rc;
     st->cap_paths = n;
     return FTN_OK;
 }
@@ -1416,7 +1422,7 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
     WfBuffers W = st->W;
     W.serial = 1; W.ser_cursor = (uint2*)st->ser_mem[0]; W.ser_pfilm = (float2*)st->ser_mem[1]; W.ser_retired = (unsigned char*)st->ser_mem[2]; W.dfd = (float4*)st->ser_mem[3];
     W.n_slots = 0; W.samples = 1; W.n_paths = n_tiles; W.first_sample = 0; W.seg_cap = (uint32_t)st->cap_paths; W.valid_per_sample = 0;
-    W.gen_blocks = 0; W.rng_replay = 0; W.br = nullptr;
+    W.gen_blocks = 0; W.rng_replay = 0; W.br = nullptr; W.pd = nullptr;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     const bool spheres = P.S.n_spheres != 0;
@@ -1552,6 +1558,7 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     /* the path integrator's streams replayed from the sample key instead of carried (WfBuffers::rng_replay): when the draw count fits its 9 bits */
     W.rng_replay = (!dl_mode && 5u + 8u * ((uint32_t)P.max_depth + 1u) <= 511u && knob("FTN_RNG_REPLAY", 1)) ? 1u : 0u;      /* shading 101.7 -> 96.9 ms per step */
     W.br = (!dl_mode && knob("FTN_WF_BR", 1)) ? st->br : nullptr;
+    W.pd = (!dl_mode && knob("FTN_WF_PD", 1)) ? st->pd : nullptr;
     W.gen_blocks = knob("FTN_GEN_BLOCKS", 1);      /* camera rays of a full tile queued in 2 x 2 pixel blocks: first closest-hit launch 37.3 -> 36.6 ms */
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));

@@ -31,6 +31,8 @@ struct WfBuffers {
                                  * rad's -- the two are always read and written together, one scattered access instead of two; rad[] then only receives FINAL radiance */
     ulonglong2 *rng01, *rng23;  /* Xoshiro256+ state */
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
+    float4* pd;                 /* path integrator (NULL: not used): the three pending terms of a path in one 64-byte record, pd[4 p + k] = pend<k>[p] (the fourth
+                                 * float4 is padding: a record never straddles a 128-byte line) -- written together, read together */
     uint32_t *q_active[2], *q_closest, *q_shadow;   /* active-queue entries carry WF_Q_FIN / WF_Q_DEPTH in their top bits */
     uint32_t* q_sorted;         /* the active queue grouped by shading class (material-sorted shading) */
     uint32_t* cls;              /* per-class path counts, one 128-byte line each (CTR(k)) */
