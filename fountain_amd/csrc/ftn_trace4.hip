@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
                 ray_setup<SPHERES>(R, a, b);
                 St.sp = St.base; L.cur = 0; found = false;
                 if (ray_is_exceptional(R.o.x, R.o.y, R.o.z, R.inv.x, R.inv.y, R.inv.z)) hand_back = true;
-                else if (S.n_nodes == 0 || !slab_test(rlo, rhi, R.o, R.inv, R.t_max)) W.occluded[rid] = 0;
+                else if (S.n_nodes == 0 || !slab_test(rlo, rhi, R.o, R.inv, R.t_max)) store_occluded(W, rid, false);
                 else if (S.root_is_leaf) { L.lp = 0; L.mode = T4_LEAF; }
                 else L.mode = T4_NODE;
             }
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) k_wf_trace4_any(DScene S, WfBuffers W, co
                 } else L.lp++;
             }
         }
-        if (L.finish) { W.occluded[rid] = found ? 1 : 0; L.mode = T4_IDLE; }
+        if (L.finish) { store_occluded(W, rid, found); L.mode = T4_IDLE; }
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { n_rec += __shfl_down(n_rec, off, 64); n_prim += __shfl_down(n_prim, off, 64); }
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256) k_wf_trace8_any(DScene S, WfBuffers W, co
                 ray_setup<false>(R, a, b);
                 St.sp = St.base; L.cur = 0; found = false;
                 if (ray_is_exceptional(R.o.x, R.o.y, R.o.z, R.inv.x, R.inv.y, R.inv.z) || ray_out_of_range8(R.o.x, R.o.y, R.o.z, R.inv.x, R.inv.y, R.inv.z)) hand_back = true;
-                else if (!slab_test(rlo, rhi, R.o, R.inv, R.t_max)) W.occluded[rid] = 0;       /* the root's own box (bvh.rs:228 at node 0) */
+                else if (!slab_test(rlo, rhi, R.o, R.inv, R.t_max)) store_occluded(W, rid, false);       /* the root's own box (bvh.rs:228 at node 0) */
                 else L.mode = T8_NODE;
             }
             if (__ballot(hand_back) != 0) wave_push(hand_back, q_entry, W.q_exc_any, &W.counters[CTR(33)]);
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(256) k_wf_trace8_any(DScene S, WfBuffers W, co
                 } else { L.lp = prim + 1u; L.mode = T8_LEAF_IN; }
             }
         }
-        if (L.finish) { W.occluded[rid] = found ? 1 : 0; L.mode = T8_IDLE; }
+        if (L.finish) { store_occluded(W, rid, found); L.mode = T8_IDLE; }
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { n_rec += __shfl_down(n_rec, off, 64); n_prim += __shfl_down(n_prim, off, 64); }

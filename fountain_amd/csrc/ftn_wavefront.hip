@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
                 sptr = st_base; cur = 0; found = false; hprim = -1; hb0 = 0.0f; hb1 = 0.0f; hb2 = 0.0f;
                 mode = TM_NODE;
                 if (S.n_nodes == 0) {   /* empty scene: immediate miss */
-                    if (ANY) W.occluded[rid] = 0; else { W.hit[rid] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[rid] = -1; }
+                    if (ANY) store_occluded(W, rid, false); else { W.hit[rid] = make_float4(FTN_INF, 0.0f, 0.0f, 0.0f); W.hit_prim[rid] = -1; }
                     mode = TM_IDLE;
                 }
             }
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_wf_trace(DScene S, WfBuffers W, const u
             }
         }
         if (finish) {
-            if (ANY) W.occluded[rid] = found ? 1 : 0;
+            if (ANY) store_occluded(W, rid, found);
             else { W.hit[rid] = make_float4(found ? t_max : FTN_INF, hb0, hb1, hb2); W.hit_prim[rid] = hprim; }
             mode = TM_IDLE;
         }
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
                 sx = -dperm.x / dperm.z; sy = -dperm.y / dperm.z; sz = 1.0f / dperm.z;
                 sptr = st_base; cur = 0; found = false;
                 /* the root's own box test (bvh.rs:228-230) */
-                if (S.n_nodes == 0 || !slab_test(rlo, rhi, o, inv, t_max)) { W.occluded[rid] = 0; mode = TM_IDLE; }
+                if (S.n_nodes == 0 || !slab_test(rlo, rhi, o, inv, t_max)) { store_occluded(W, rid, false); mode = TM_IDLE; }
                 else if (S.root_is_leaf) { lp = 0; mode = TM_LEAF; }
                 else mode = TM_NODE;
             }
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) k_wf_trace_any2(DScene S, WfBuffers W, co
                 } else lp++;
             }
         }
-        if (finish) { W.occluded[rid] = found ? 1 : 0; mode = TM_IDLE; }
+        if (finish) { store_occluded(W, rid, found); mode = TM_IDLE; }
     }
 #ifdef FTN_DRAIN_PROBE
     if (lane == 0) {
@@ -460,16 +460,17 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
             uint32_t ps = __float_as_uint(bq.w);
             /* ---- finish the previous bounce's estimate_direct (integrator/mod.rs:330-392) */
             if (ps & PS_DIRECT) {
-                float4 q0, q1, q2;
-                if (W.pd) { const float4* Q = W.pd + 4 * (size_t)p; q0 = Q[0]; q1 = Q[1]; q2 = Q[2]; } else { q0 = W.pend0[p]; q1 = W.pend1[p]; q2 = W.pend2[p]; }
+                float4 q0, q1, q2, q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (W.pd) { const float4* Q = W.pd + 4 * (size_t)p; q0 = Q[0]; q1 = Q[1]; q2 = Q[2]; if (W.pd_md) q3 = Q[3]; } else { q0 = W.pend0[p]; q1 = W.pend1[p]; q2 = W.pend2[p]; }
+                const uint32_t occ_word = __float_as_uint(q3.w);      /* pd_occ: the any-hit results of this path's two rays (store_occluded) */
                 Rgb radiance(0.0f);
-                if ((ps & PS_SHADOW) && !W.occluded[p]) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
+                if ((ps & PS_SHADOW) && !(W.pd_occ ? (occ_word & 0xffu) != 0u : W.occluded[p] != 0)) radiance = radiance + Rgb(q0.x, q0.y, q0.z);
                 if (ps & PS_MIS_ANY) {                           /* infinite light: the BSDF-sampled ray either escapes to it or contributes nothing (mod.rs:367-384) */
                     const int light_index = (int)__float_as_uint(lq.w);
                     const DLight& Lt = ENV ? S.env0 : S.lights[light_index];
-                    const float4 md = W.ray[2 * (size_t)(p + W.n_paths) + 1];
+                    const float4 md = W.pd_md ? q3 : W.ray[2 * (size_t)(p + W.n_paths) + 1];
                     Rgb inc(0.0f);
-                    if (!W.occluded[p + W.n_paths]) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
+                    if (!(W.pd_occ ? (occ_word & 0xff00u) != 0u : W.occluded[p + W.n_paths] != 0)) inc = light_Le_env(Lt, V3(md.x, md.y, md.z));
                     if (!inc.is_black()) radiance = radiance + Rgb(q1.x, q1.y, q1.z) * inc * q0.w / q1.w;
                 } else if (ps & PS_MIS) {
                     const int light_index = (int)__float_as_uint(lq.w);
@@ -568,7 +569,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                 const uint32_t flags = T_ALL & ~T_SPECULAR;
                                 const bool delta = !ENV && (Lt.kind == LK_POINT || Lt.kind == LK_DISTANT);
                                 ps |= PS_DIRECT; light_word = ln;
-                                Rgb ld(0.0f); float mis_w = 0.0f, mis_pdf = 1.0f; Rgb mis_f(0.0f);
+                                Rgb ld(0.0f); float mis_w = 0.0f, mis_pdf = 1.0f; Rgb mis_f(0.0f); V3 mis_d(0.0f, 0.0f, 0.0f);
                                 DLiSample ls = ENV ? light_sample_env(Lt, si.hit, ul) : light_sample(S, Lt, si.hit, ul);
                                 if (ls.pdf > 0.0f && !ls.radiance.is_black()) {
                                     Rgb f = bsdf_f(B, si.wo, ls.wi, flags) * abs_dot(ls.wi, si.shading_n);
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                                 DRay mr = spawn_ray(si.hit, sc.wi);
                                                 W.ray[2 * (size_t)(p + W.n_paths)] = make_float4(mr.o.x, mr.o.y, mr.o.z, 0.0f);
                                                 W.ray[2 * (size_t)(p + W.n_paths) + 1] = make_float4(mr.d.x, mr.d.y, mr.d.z, mr.t_max);
-                                                mis_f = f; mis_pdf = sc.pdf;
+                                                mis_f = f; mis_pdf = sc.pdf; mis_d = mr.d;
                                                 if (W.mis_any && (ENV || Lt.kind == LK_INFINITE)) { ps |= PS_MIS_ANY; push_mis_any = true; } else { ps |= PS_MIS; push_mis = true; }
                                             }
                                         }
@@ -604,6 +605,7 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
                                 if (W.pd) {
                                     float4* Q = W.pd + 4 * (size_t)p;
                                     Q[0] = make_float4(ld.r, ld.g, ld.b, mis_w); Q[1] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf); Q[2] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                                    if (W.pd_md) Q[3] = make_float4(mis_d.x, mis_d.y, mis_d.z, 0.0f);      /* w: the any-hit kernels' result bytes */
                                 } else {
                                     W.pend0[p] = make_float4(ld.r, ld.g, ld.b, mis_w);
                                     W.pend1[p] = make_float4(mis_f.r, mis_f.g, mis_f.b, mis_pdf);
@@ -1422,7 +1424,7 @@ static int wavefront_render_serial(WavefrontState* st, const RenderParams& P, ui
     WfBuffers W = st->W;
     W.serial = 1; W.ser_cursor = (uint2*)st->ser_mem[0]; W.ser_pfilm = (float2*)st->ser_mem[1]; W.ser_retired = (unsigned char*)st->ser_mem[2]; W.dfd = (float4*)st->ser_mem[3];
     W.n_slots = 0; W.samples = 1; W.n_paths = n_tiles; W.first_sample = 0; W.seg_cap = (uint32_t)st->cap_paths; W.valid_per_sample = 0;
-    W.gen_blocks = 0; W.rng_replay = 0; W.br = nullptr; W.pd = nullptr;
+    W.gen_blocks = 0; W.rng_replay = 0; W.br = nullptr; W.pd = nullptr; W.pd_md = 0; W.pd_occ = 0;
     const int count_mode = count ? (count_production ? 2 : 1) : 0;
     W.mis_any = ((!count || count_production) && knob("FTN_MIS_ANY", 1)) ? 1u : 0u;
     const bool spheres = P.S.n_spheres != 0;
@@ -1558,7 +1560,9 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
     /* the path integrator's streams replayed from the sample key instead of carried (WfBuffers::rng_replay): when the draw count fits its 9 bits */
     W.rng_replay = (!dl_mode && 5u + 8u * ((uint32_t)P.max_depth + 1u) <= 511u && knob("FTN_RNG_REPLAY", 1)) ? 1u : 0u;      /* shading 101.7 -> 96.9 ms per step */
     W.br = (!dl_mode && knob("FTN_WF_BR", 1)) ? st->br : nullptr;
-    W.pd = (!dl_mode && knob("FTN_WF_PD", 1)) ? st->pd : nullptr;
+    W.pd = (!dl_mode && knob("FTN_WF_PD", 3)) ? st->pd : nullptr;      /* 1: the three pending terms in one record; 2: + the MIS ray's direction; 3: + the any-hit results (WfBuffers::pd_md, pd_occ) */
+    W.pd_md = (W.pd && knob("FTN_WF_PD", 3) >= 2) ? 1u : 0u;
+    W.pd_occ = (W.pd && knob("FTN_WF_PD", 3) >= 3) ? 1u : 0u;
     W.gen_blocks = knob("FTN_GEN_BLOCKS", 1);      /* camera rays of a full tile queued in 2 x 2 pixel blocks: first closest-hit launch 37.3 -> 36.6 ms */
     const size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
     const unsigned blocks_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));

@@ -33,6 +33,9 @@ struct WfBuffers {
     float4 *pend0, *pend1, *pend2;   /* (Ld_light.xyz, weight) (f.xyz, pdf) (beta_prev.xyz, -) */
     float4* pd;                 /* path integrator (NULL: not used): the three pending terms of a path in one 64-byte record, pd[4 p + k] = pend<k>[p] (the fourth
                                  * float4 is padding: a record never straddles a 128-byte line) -- written together, read together */
+    uint32_t pd_md, pd_occ;     /* 1 (with pd): the fourth float4 of a path's record is used too -- xyz = direction of its MIS ray (what the next event needs of that
+                                 * ray when it went through the any-hit kernel), and the any-hit kernels store their results in the bytes of w (byte 0: the shadow
+                                 * ray's, byte 1: the MIS ray's; store_occluded) instead of occluded[]: the next event finds them in the line it reads anyway */
     uint32_t *q_active[2], *q_closest, *q_shadow;   /* active-queue entries carry WF_Q_FIN / WF_Q_DEPTH in their top bits */
     uint32_t* q_sorted;         /* the active queue grouped by shading class (material-sorted shading) */
     uint32_t* cls;              /* per-class path counts, one 128-byte line each (CTR(k)) */
@@ -108,6 +111,16 @@ __device__ inline void block_push(const bool (&pred)[NQ], const uint32_t (&value
         }
     }
     __syncthreads();   /* s_cnt / s_base are reused by the next round */
+}
+
+/* result of an any-hit ray; slot as load_queued_ray<true> gives it ([0, n_paths) shadow rays, [n_paths, 2 n_paths) MIS rays) */
+__device__ inline void store_occluded(const WfBuffers& W, uint32_t slot, bool occ) {
+    if (W.pd_occ) {
+        if (!occ) return;        /* the shading event that queued the ray wrote the record with w = 0: "not occluded" is already there */
+        const bool mis = slot >= W.n_paths;
+        const uint32_t p = mis ? slot - W.n_paths : slot;
+        ((unsigned char*)(W.pd + 4 * (size_t)p + 3))[12 + (mis ? 1 : 0)] = occ ? 1 : 0;
+    } else W.occluded[slot] = occ ? 1 : 0;
 }
 
 /* A queue entry is a path id; WF_MIS_BIT marks the path's MIS ray (record n_paths + id) instead of its continuation ray (closest-hit

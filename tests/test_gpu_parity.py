@@ -775,6 +775,43 @@ def test_launch_schedules_change_nothing(gpu, monkeypatch):
         assert np.array_equal(bits(v[0]), bits(out["default"][0])) and v[1:] == out["default"][1:], name
 
 
+def test_path_record_layouts_change_nothing(gpu, orc_det, monkeypatch):
+    """where the path integrator keeps a path's state between two events -- SoA arrays (FTN_WF_BR=0, FTN_WF_PD=0), throughput + radiance in one
+    32-byte record, the pending direct-light terms in one 64-byte record (FTN_WF_PD=1), with the MIS ray's direction behind them (2) and the
+    any-hit kernels' results in the record's last word (3, the default: an any-hit kernel then only stores "occluded", the event that queued
+    the ray having written "not occluded") -- and whether its Xoshiro stream is carried or replayed decide where bytes live, never their
+    value: same film bit for bit, same counts, and the default equals the oracle.  Scenes: triangles under an environment map (shadow and
+    MIS rays through k_wf_trace8_any), spheres of every material under one (the four-box any-hit kernel), the all-materials scene (area
+    lights: MIS rays through the closest-hit kernel)"""
+
+    def cubes(be):
+        b, cam, res = scenes.instanced_cubes(be, n_copies=5, res=(96, 96), env_n=32)
+        return b.create_scene(), cam, res
+
+    def materials(be):
+        b, cam, res = _materials_scene(be)
+        return b.create_scene(), cam, res
+
+    for make, smp in ((cubes, RandomSampler(8, 2, indexed=True)), (lambda be: _env_only_scene(be, res=(96, 64)), RandomSampler(8, 2, indexed=True)), (materials, RandomSampler(4, 5, indexed=True))):
+        sc, cam, res = make(gpu)
+        si = SamplerIntegrator(cam, PathIntegrator.new(5, 1.0))
+        out = {}
+        for name, env in (("default", {}), ("soa", {"FTN_WF_BR": "0", "FTN_WF_PD": "0"}), ("pd1", {"FTN_WF_PD": "1"}), ("pd2", {"FTN_WF_PD": "2"}), ("pd3 br0", {"FTN_WF_PD": "3", "FTN_WF_BR": "0"}),
+                          ("carried streams", {"FTN_RNG_REPLAY": "0"}), ("two streams", {"FTN_WF_OVERLAP": "1"})):
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            f = Film(gpu, res)
+            st = si.render_parallel(sc, f, smp, pipeline=WAVE)
+            out[name] = (f.pixels, st["rays_closest"], st["rays_any"], st["spill_samples"])
+            for k in env: monkeypatch.delenv(k)
+        for name, v in out.items():
+            assert np.array_equal(bits(v[0]), bits(out["default"][0])) and v[1:3] == out["default"][1:3], name
+        sco, camo, _ = make(orc_det)
+        fo = Film(orc_det, res)
+        sto = SamplerIntegrator(camo, PathIntegrator.new(5, 1.0)).render_parallel(sco, fo, smp)
+        assert_film_equal(out["default"][0], fo.pixels, out["default"][3], "path records vs oracle")
+        assert out["default"][1:3] == (sto["rays_closest"], sto["rays_any"])
+
+
 def test_environment_cell_records_change_nothing(gpu, monkeypatch):
     """the cell records of a square environment map (built at scene creation; FTN_ENV_CELLS=0: not built; FTN_ENV_CELLS_USE=0: built but the
     environment-only kernels read the plain tables): same film, same counts, on both pipelines"""
