@@ -944,7 +944,8 @@ __device__ inline void dist1d_sample(const float* func, const float* cdf, float 
 FTN_DEV_NOINLINE Rgb light_Le_env(const DLight& L, V3 dir) {    /* infinite.rs:156-164 */
     V3 w = normalize(m4_vector(L.w2l, dir));
     V2 st(spherical_phi(w) * (1.0f / (2.0f * FTN_PI)), spherical_theta(w) * FTN_INV_PI);
-    if (L.cells) { int cx, cy; Rgb r; env_cell_of(L, st, &cx, &cy); if (env_cell_lookup(L, st, cx, cy, &r)) return r; }
+    /* the plain texel table (12 MB at 1024^2: mostly served by the caches), not the cell records (128 MB: a miss each time) -- those pay where
+     * a light SAMPLE needs the neighbourhood and the function value of the cell its search ended in (light_sample_env) */
     return env_lookup(L, st);
 }
 __device__ inline Rgb scene_env_Le(const DScene& S, V3 dir) {    /* scene/mod.rs:59-64: sum over all lights (non-infinite give 0) */
@@ -984,7 +985,7 @@ __device__ inline float light_pdf_env(const DLight& L, V3 wi) {                 
     float px = phi * (1.0f / (2.0f * FTN_PI)), py = theta * FTN_INV_PI;
     long long iu = f2usize(px * (float)L.nu); if (iu > (long long)L.nu - 1) iu = (long long)L.nu - 1;
     long long iv = f2usize(py * (float)L.nv); if (iv > (long long)L.nv - 1) iv = (long long)L.nv - 1;
-    const float fv = L.cells ? env_cell_func(L, (uint32_t)iu, (uint32_t)iv) : L.cond_func[(size_t)iv * L.nu + iu];
+    const float fv = L.cond_func[(size_t)iv * L.nu + iu];      /* (the 4-byte table, not the cell record: 4 MB stay cached where 128 MB do not) */
     return (fv / L.marg_integral) / (2.0f * FTN_PI * FTN_PI * sth);
 }
 FTN_DEV_NOINLINE DLiSample light_sample(const DScene& S, const DLight& L, const DSurfHit& ref, V2 u) {
