@@ -661,6 +661,12 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
     if (err) atomicCAS(&P.stats->error, 0, err);
 }
 
+/* resident workgroups of a shade kernel per CU (registers, LDS), asked once per variant */
+template <bool TEX, int MT, bool ENV> static unsigned shade_wgs_per_cu() {
+    static const unsigned nb = [] { int v = 0; return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_wf_shade<TEX, MT, ENV>, 256, 0) == hipSuccess && v >= 1) ? (unsigned)(v > 8 ? 8 : v) : 3u; }();
+    return nb;
+}
+
 /* ------------------------------------------------------------------ DirectLightingIntegrator / WhittedIntegrator through the queues
  * (direct_lighting.rs:50-110, whitted.rs:20-75, specular_reflect / specular_transmit integrator/mod.rs:39-178)
  *
@@ -1678,7 +1684,12 @@ int wavefront_render(WavefrontState** state, const RenderParams& P0, const std::
                     else hipLaunchKernelGGL((k_wf_shade<false, -1, false>), sgrid, dim3(256), 0, stream, P, W, in_q, 0xffu, first);
                 } else {   /* one launch per material type present in the scene + one for the classes without a BSDF */
                     const bool env = P.S.env_only && knob("FTN_SHADE_ENV", 1);        /* lit by one InfiniteAreaLight: the variants specialised for it */
-#define FTN_SH2(T, M, E, mask) hipLaunchKernelGGL((k_wf_shade<T, M, E>), sgrid, dim3(256), 0, stream, P, W, in_q, mask, first)
+                    /* workgroups per CU: what the kernel's registers let a CU hold at once (x 2 for the light kernel of the classes without a BSDF) -- every
+                     * workgroup loops over an equal share of its class, so a grid of 8 per CU against 3 resident ran its last third at 2/3 of the
+                     * machine (shading 83.2 -> 81.9 ms; 4 per CU: 97 ms); FTN_SHADE_GRID / FTN_SHADE_GRID_NOBSDF set it by hand */
+                    const unsigned grid_k = knob("FTN_SHADE_GRID", 0), grid_k_nb = knob("FTN_SHADE_GRID_NOBSDF", 0);
+#define FTN_SH2(T, M, E, mask) do { const unsigned per_cu = (M) == -2 ? (grid_k_nb ? grid_k_nb : 2u * shade_wgs_per_cu<T, M, E>()) : (grid_k ? grid_k : shade_wgs_per_cu<T, M, E>()); \
+                                    hipLaunchKernelGGL((k_wf_shade<T, M, E>), dim3(std::min<unsigned>((unsigned)st->n_cu * per_cu, (W.n_paths + 255) / 256)), dim3(256), 0, stream, P, W, in_q, mask, first); } while (0)
 #define FTN_SH(M, mask) do { if (tex) { if (env) FTN_SH2(true, M, true, mask); else FTN_SH2(true, M, false, mask); } \
                              else { if (env) FTN_SH2(false, M, true, mask); else FTN_SH2(false, M, false, mask); } } while (0)
                     FTN_SH(-2, 0x83u);
