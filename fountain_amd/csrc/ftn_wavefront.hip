@@ -497,9 +497,18 @@ __global__ void __launch_bounds__(256, (MT == -1 ? FTN_SHADE_MIN_WAVES : (MT == 
             if (!(ps & PS_ALIVE)) {
                 W.rad[p] = make_float4(L.r, L.g, L.b, 0.0f);     /* path finished: final radiance (the rest of its state is never read again) */
             } else {
-                const float4 ro = W.ray[2 * (size_t)(p)], rdv = W.ray[2 * (size_t)(p) + 1];
-                DRay ray0; ray0.o = V3(ro.x, ro.y, ro.z); ray0.d = V3(rdv.x, rdv.y, rdv.z); ray0.t_max = rdv.w; ray0.time = 0.0f;
-                const DHit h = load_hit(W, p);
+                DRay ray0; ray0.o = V3(0.0f, 0.0f, 0.0f); ray0.d = V3(0.0f, 0.0f, 1.0f); ray0.t_max = FTN_INF; ray0.time = 0.0f;
+                DHit h; h.t = FTN_INF; h.b0 = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f; h.prim = -1;
+                /* the light kernel of the classes without a BSDF mostly sees paths whose ray escaped: all such a path needs is that fact (hit_prim),
+                 * unless it looks at the environment along the ray -- camera rays and specular bounces (path.rs:45-58).  Its ray and hit records are
+                 * then not read at all */
+                bool need_ray = true;
+                if (MT == -2 && !first) { h.prim = W.hit_prim[p]; need_ray = h.prim >= 0 || (ps & PS_BOUNCE_MASK) == 0u || (ps & PS_SPECULAR) != 0u; }
+                if (need_ray) {
+                    const float4 ro = W.ray[2 * (size_t)(p)], rdv = W.ray[2 * (size_t)(p) + 1];
+                    ray0.o = V3(ro.x, ro.y, ro.z); ray0.d = V3(rdv.x, rdv.y, rdv.z); ray0.t_max = rdv.w;
+                    h = load_hit(W, p);
+                }
                 const bool hit = h.prim >= 0;
                 uint32_t bounces = ps & PS_BOUNCE_MASK;
                 const bool specular_bounce = (ps & PS_SPECULAR) != 0;
